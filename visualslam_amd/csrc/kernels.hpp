@@ -1,0 +1,81 @@
+// kernels.hpp -- internal launch interface between the HIP kernels (*.hip) and the C-ABI
+// layers (nvxcu_api.cpp, the OpenVX-subset runtime).  Nothing here is exported.
+//
+// All launchers are asynchronous on `stream` and allocate nothing.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include <hip/hip_runtime_api.h>
+
+namespace vsa {
+
+constexpr int kMaxPyrLevels = 10;
+constexpr int kLkMinWin = 3;
+constexpr int kLkMaxWin = 32;
+
+enum ItemKind : int { kPoint2f = 0, kKeypointf = 1 };
+enum Detector : int { kHarris = 0, kFast = 1 };
+
+struct ImageView {
+    const uint8_t *ptr;
+    uint32_t pitch, width, height;
+};
+
+struct PyramidView {
+    const uint8_t *ptr[kMaxPyrLevels];
+    uint32_t pitch[kMaxPyrLevels];
+    uint32_t width[kMaxPyrLevels];
+    uint32_t height[kMaxPyrLevels];
+    uint32_t levels;
+};
+
+// RGBX -> U8 luma, (54 R + 183 G + 19 B + 128) >> 8
+hipError_t launch_rgbx_to_u8(const ImageView &src, uint8_t *dst, uint32_t dst_pitch, hipStream_t stream);
+
+// dst(x,y) = (sum_{i,j} w_i w_j src(clamp(2x+i-2), clamp(2y+j-2)) + 128) >> 8, w = [1 4 6 4 1]
+hipError_t launch_gaussian_half(const ImageView &src, uint8_t *dst, uint32_t dst_pitch,
+                                uint32_t dst_width, uint32_t dst_height, hipStream_t stream);
+
+struct CornerTrackParams {
+    Detector detector;
+    ImageView image;
+    const uint8_t *mask;          // may be null
+    uint32_t mask_pitch;
+    ItemKind item;
+    const void *tracked;          // may be null
+    const uint32_t *tracked_count;
+    uint32_t tracked_capacity;
+    void *out;
+    uint32_t *out_count;
+    uint32_t out_capacity;
+    size_t *num_corners;          // may be null (device pointer)
+    float harris_k;
+    float threshold;              // Harris threshold, or (float)FAST threshold
+    uint32_t fast_n;
+    uint32_t cell_size;
+    void *scratch;                // corner_track_scratch_bytes() bytes, 8-byte aligned
+};
+
+size_t corner_track_scratch_bytes(uint32_t width, uint32_t height, uint32_t cell_size);
+hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream);
+
+struct PyrLKParams {
+    PyramidView prev, curr;
+    ItemKind item;
+    const void *prev_pts;
+    const uint32_t *prev_count;
+    const void *estimates;        // may alias out
+    void *out;
+    uint32_t *out_count;          // may alias prev_count's sibling; written with the item count
+    uint32_t capacity;
+    int use_epsilon;
+    uint32_t max_iterations;
+    float epsilon;
+    uint32_t window;
+};
+
+hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream);
+
+}  // namespace vsa
