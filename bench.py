@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec @1080p with 4k PyrLK tracks (BASELINE.json metric), N GPUs of one node.
+
+A step = one frame on each of S independent camera streams of this GPU (colour convert ->
+5-level Gaussian pyramid -> PyrLK 21x21 on <=4096 points -> Harris track/merge), inputs resident
+in HBM (a ring of pre-generated RGBX frames).  Streams are sharded one-or-more per GPU; there is
+no data-path collective -- the process group only carries the timing
+barrier and the max-over-ranks reduction.
+
+  python bench.py [--gpus N --steps K --warmup W --streams S]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# SURVEY.md section 8d, configs[1]: algorithmic (compulsory, unique) bytes per frame
+WIDTH, HEIGHT, LEVELS, CAPACITY, CELL, WIN, ITERS = 1920, 1080, 5, 4096, 18, 21, 5
+BYTES_PYRAMID = 2754000 + 688560
+BYTES_DETECT = 2073600 + 32768
+BYTES_LK = 5524320 + 65536          # both pyramids read once + 16 B per point: the PyrLK launch
+BYTES_CVT = 10368000
+BYTES_FRAME = BYTES_PYRAMID + BYTES_DETECT + BYTES_LK + BYTES_CVT
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
+WORKLOAD = "1080p synthetic RGBX frames, 5-level pyramid, 4k Harris features (cell 18), 21x21 PyrLK window, 5 iters"
+
+
+def shard_streams(total_streams, world_size, rank):
+    """camera stream s runs on rank s % world_size (independent units, no exchange step)"""
+    return [s for s in range(total_streams) if s % world_size == rank]
+
+
+def reduce_max(value, world_size):
+    if world_size == 1:
+        return value
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier(world_size):
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def cpu_baseline(frames_rgbx, params, budget_s=12.0, max_frames=48):
+    """The oracle (a port: the reference implementation is closed-source) timed on this host's
+    cores, OpenMP over points/rows, on a bounded sample of the same workload."""
+    from oracle.pipeline import OracleTracker
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    trk = OracleTracker(params, omp=True)
+    trk.init(frames_rgbx[0])
+    n, t0 = 0, time.perf_counter()
+    while n < max_frames:
+        trk.track(frames_rgbx[(n + 1) % len(frames_rgbx)])
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} frames of the same 1080p workload through oracle/ (OpenMP, {threads} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--streams", type=int, default=4, help="camera streams per GPU")
+    ap.add_argument("--ring", type=int, default=8, help="pre-generated frames resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+
+    from visualslam_amd import nvxcu, synth
+    from visualslam_amd.devmem import DeviceImage
+    from visualslam_amd.thin_tracker import Params, ThinFeatureTracker
+
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    nvxcu.lib()
+
+    params = Params(pyr_levels=LEVELS, lk_num_iters=ITERS, lk_win_size=WIN, array_capacity=CAPACITY,
+                    detector_cell_size=CELL, use_harris_detector=True, harris_k=0.04, harris_thresh=100.0)
+
+    # weak scaling: S streams on every GPU; global stream ids sharded round-robin over ranks
+    my_streams = shard_streams(args.streams * world, world, rank)
+    assert len(my_streams) == args.streams
+
+    base = synth.base_frame(WIDTH, HEIGHT, 1234)
+    host_frames = [synth.to_rgbx(synth.gray_frame(base, t, 1234)) for t in range(args.ring)]
+    ring = [DeviceImage(WIDTH, HEIGHT, nvxcu.NVXCU_DF_IMAGE_RGBX, device).upload(f) for f in host_frames]
+
+    trackers = [ThinFeatureTracker(params, WIDTH, HEIGHT, device, torch.cuda.Stream(device)) for _ in my_streams]
+    for i, trk in enumerate(trackers):
+        trk.phase = (my_streams[i] * 3) % args.ring      # streams look at different frames
+        trk.init(ring[trk.phase].desc)
+    torch.cuda.synchronize()
+
+    def step(k):
+        for trk in trackers:
+            trk.track(ring[(trk.phase + 1 + k) % args.ring].desc)
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    barrier(world)
+    trackers[0].lk_events = []
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier(world)
+    lk_pairs, trackers[0].lk_events = trackers[0].lk_events, None
+    elapsed = reduce_max(elapsed, world)
+
+    # tracks alive at the end (diagnostic) and the PyrLK launch duration from its HIP events
+    n_tracks = [int((trk.curr_features()[:, 0] >= 0).sum()) for trk in trackers]
+    n_points = [trk.prev_pts.num_items() for trk in trackers]
+    lk_ms = float(np.mean([a.elapsed_time(b) for a, b in lk_pairs])) if lk_pairs else float("nan")
+
+    if rank == 0:
+        frames = args.steps * args.streams * world
+        fps = frames / elapsed
+        lk_gbs = BYTES_LK / (lk_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "lk_hbm_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as f:
+                traffic = json.load(f).get("bytes_per_launch")
+        out = {
+            "metric": "frames/sec @1080p with 4k PyrLK tracks",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD, "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
+                       "frame_ring": args.ring, "api": "thin C ABI (NVX/nvxcu.h), eager launches, one HIP stream per camera stream"},
+            "tracks_per_sec": fps * float(np.mean(n_tracks)),
+            "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),
+            "frame_algorithmic_GBps": BYTES_FRAME * fps / 1e9,
+            "frame_algorithmic_frac_of_hbm_peak": BYTES_FRAME * fps / 1e9 / (HBM_PEAK_GBS * world),
+            "roofline": {"kernel": "k_pyrlk<7> (PyrLK, 4096 points x 5 levels, 21x21)", "bound": "hbm",
+                         "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "launch_ms": lk_ms, "algorithmic_bytes_per_launch": BYTES_LK},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(host_frames, params)
+        print(json.dumps(out), flush=True)
+    barrier(world)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

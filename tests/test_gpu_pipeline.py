@@ -5,7 +5,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from ref_pipeline import OracleTracker
+from oracle.pipeline import OracleTracker
 from visualslam_amd import nvxcu, synth
 from visualslam_amd.devmem import DeviceImage
 from visualslam_amd.thin_tracker import Params, ThinFeatureTracker

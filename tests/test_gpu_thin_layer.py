@@ -223,10 +223,10 @@ def _lk_case(w, h, levels, seed, dx, dy, n, item_type=O.POINT2F):
     return p0, p1, kp
 
 
-def _run_lk(p0, p1, pts, est, item_type, term, eps, iters, win):
+def _run_lk(p0, p1, pts, est, item_type, term, eps, iters, win, pitch_pad=None):
     h, w = p0[0].shape
-    d0 = DevicePyramid(w, h, len(p0)).upload(p0)
-    d1 = DevicePyramid(w, h, len(p1)).upload(p1)
+    d0 = DevicePyramid(w, h, len(p0), pitch_pad=pitch_pad).upload(p0)
+    d1 = DevicePyramid(w, h, len(p1), pitch_pad=pitch_pad).upload(p1)
     it = nvxcu.NVXCU_TYPE_POINT2F if item_type == O.POINT2F else nvxcu.NVXCU_TYPE_KEYPOINTF
     old = DeviceArray(len(pts) + 3, it).upload(pts)
     new = DeviceArray(len(pts) + 3, it).upload(pts if est is None else est)
@@ -260,6 +260,27 @@ def test_pyrlk_levels_and_termination(gpu, levels, term, iters):
     got = _run_lk(p0, p1, pts, None, O.POINT2F, term, 0.01, iters, 10)
     want = O.optical_flow_pyr_lk(p0, p1, pts, None, int(term), 0.01, iters, 10)
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("win,pad", [(21, 3), (10, 1), (21, 8), (5, 12)])
+def test_pyrlk_pitch_variants(gpu, win, pad):
+    """odd pitches take the byte-gather fallback kernel, 4-aligned ones the dword kernel: same bits"""
+    p0, p1, pts = _lk_case(203, 117, 3, seed=win + pad, dx=0.7, dy=1.9, n=500)
+    got = _run_lk(p0, p1, pts, None, O.POINT2F, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 0.01, 5, win, pitch_pad=pad)
+    want = O.optical_flow_pyr_lk(p0, p1, pts, None, O.TERM_BOTH, 0.01, 5, win)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_pyrlk_large_motion_restages_search_tile(gpu):
+    """one pyramid level and a 9 px shift: the iteration walks out of the staged tile"""
+    p0, p1, _ = _lk_case(320, 240, 1, seed=31, dx=7.5, dy=-6.25, n=4)
+    rng = np.random.default_rng(8)
+    pts = np.stack([rng.uniform(30, 290, 400), rng.uniform(30, 210, 400)], 1).astype(np.float32)
+    got = _run_lk(p0, p1, pts, None, O.POINT2F, nvxcu.NVXCU_TERM_CRITERIA_ITERATIONS, 0.01, 30, 21)
+    want = O.optical_flow_pyr_lk(p0, p1, pts, None, O.TERM_ITERATIONS, 0.01, 30, 21)
+    assert got.tobytes() == want.tobytes()
+    moved = np.abs(got - pts).max(axis=1)
+    assert (moved[got[:, 0] >= 0] > 5.0).sum() > 50    # many windows really left the 4 px margin
 
 
 def test_pyrlk_recovers_known_translation(gpu):

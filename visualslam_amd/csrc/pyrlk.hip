@@ -1,21 +1,25 @@
-// pyrlk.hip -- sparse pyramidal Lucas-Kanade optical flow, one wavefront per feature.
+// pyrlk.hip -- sparse pyramidal Lucas-Kanade optical flow, one wavefront per feature (fast path).
 //
 // Reference call sites replaced: vxOpticalFlowPyrLKNode / nvxcuOpticalFlowPyrLK
 // (demos/feature_tracker/feature_tracker.cpp:402-412, demos/feature_tracker_nvxcu/feature_tracker_nvxcu.cpp:297-301,
 // samples/object_tracker_nvxcu/object_tracker_keypoint_nvxcu.cpp:1791-1828).  Semantics and the exact
 // floating-point operation order: oracle/vxoracle.c (lk_track_one) -- results are bit-identical.
 //
-// Design (MI355X): a 64-lane wave owns one feature for all pyramid levels, coarse to fine.
-//   * window pixels are dealt to lanes as (row, segment): lane l handles `seglen` consecutive
-//     pixels of one window row, so the two bilinear source rows are read from LDS once per lane
-//     and each column is shared by two neighbouring pixels;
-//   * per level the (win+3)^2 template patch is staged in LDS, Scharr gradients are computed on
-//     the integer grid into LDS, and the bilinear-resampled template I, Ix, Iy stay in REGISTERS
-//     for all iterations;
-//   * the search image is staged once per level as a (win+1+2M)^2 LDS tile around the predicted
-//     position; an iteration that walks out of the tile restages it (wave-uniform branch);
-//   * the 2x2 normal equations live in registers; sums are combined by a cross-lane butterfly
-//     whose order the oracle mirrors.
+// Design (MI355X, gfx950):
+//   * a 64-lane wave owns one feature for all pyramid levels, coarse to fine; window pixels are
+//     dealt to lanes as (row, segment of `seglen` consecutive pixels), so a lane streams along two
+//     LDS rows and every column it reads serves two neighbouring pixels;
+//   * tiles are fetched as ALIGNED DWORDS (4 pixels per lane per load, all loads of a tile issued
+//     back to back into registers), converted once and written to LDS as one ds_write_b128 each;
+//     tiles that poke out of the image are patched per byte with the row's edge pixels (replicate);
+//   * latency hiding inside the wave: the search tile's loads are in flight while the template is
+//     resampled, and the next level's template loads are in flight while this level iterates;
+//   * Scharr gradients are never stored: each lane derives them for its segment from four LDS rows
+//     (exact small integers, so the separable evaluation order is free), then resamples I, Ix, Iy
+//     bilinearly into REGISTERS where they stay for all iterations;
+//   * packed f32 math (v_pk_fma_f32) carries the (top,bottom) row pair and the (Ix,Iy) pair;
+//   * sums are combined by DPP row reductions + 4 readlanes, in the butterfly order the oracle mirrors;
+//   * the 2x2 normal equations are solved in registers, wave-uniformly.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -26,6 +30,8 @@ namespace vsa {
 namespace {
 
 constexpr int LK_MARGIN = 4;  // search tile margin M (pixels) on each side of the window
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct LKArgs {
     PyramidView prev, curr;
@@ -39,7 +45,7 @@ struct LKArgs {
     int use_eps;
     uint32_t max_it;
     float eps2;
-    int win, half, segs, seglen, lanes;
+    int win, half, segs, seglen, lanes, lds_floats;
 };
 
 struct KeypointF {
@@ -48,38 +54,103 @@ struct KeypointF {
     float error;
 };
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int l)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// Pairwise butterfly (offsets 1,2,4,8,16,32); every lane ends with the same bits.  Within a row of
+// 16 the partner choice of steps 4 and 8 (mirrors) is immaterial because partial sums are already
+// uniform inside each group; rows are combined as (r0+r1)+(r2+r3).  Needs all 64 lanes active.
 __device__ __forceinline__ float wave_sum(float v)
 {
-    // pairwise butterfly, offsets 1,2,4,..,32: every lane ends with the same bits
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    const float r0 = lane_bcast(v, 0), r1 = lane_bcast(v, 16), r2 = lane_bcast(v, 32), r3 = lane_bcast(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat(float x) { return (v2f){ x, x }; }
+
+// ---- dword tile staging ----------------------------------------------------------------------
+// A tile of `n` rows x `n` columns with origin (x0,y0) is fetched as n x nd aligned dwords starting
+// at column xa = floor4(x0); LDS image: row r, dword d -> floats [4*(r*nd+d) .. +3], so tile
+// element (r,c) lives at r*4*nd + (x0-xa) + c.
+template <int NL>
+struct TileLoad {
+    uint32_t v[NL];
+    uint32_t edge[NL];   // row[0] | row[w-1] << 8, only when the tile is not inside the image
+};
+
+template <int NL>
+__device__ __forceinline__ void tile_issue(TileLoad<NL> &t, const uint8_t *img, uint32_t pitch, int w, int h,
+                                           int x0, int y0, int n, int nd, bool inside, int lane)
+{
+    const int xa = x0 & ~3;
+    const float inv_nd = 1.0f / (float)nd;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-__device__ __forceinline__ float bilerp(float a, float b, float c, float d, float fx, float fy)
-{
-    const float top = fmaf(fx, b - a, a);
-    const float bot = fmaf(fx, d - c, c);
-    return fmaf(fy, bot - top, top);
-}
-
-// stage an n x n tile of a U8 level into LDS as float, replicate-clamped
-__device__ __forceinline__ void stage_tile(float *dst, int n, const uint8_t *img, uint32_t pitch, int w, int h,
-                                           int x0, int y0, int lane)
-{
-    const float inv = 1.0f / (float)n;
-    for (int i = lane; i < n * n; i += 64) {
-        const int r = (int)(((float)i + 0.5f) * inv);
-        const int c = i - r * n;
+    for (int i = 0; i < NL; ++i) {
+        // lanes past the end repeat the last dword (same LDS slot, same data): no divergence
+        const int idx = min(lane + 64 * i, n * nd - 1);
+        const int r = (int)(((float)idx + 0.5f) * inv_nd);
+        const int d = idx - r * nd;
         const int gy = min(max(y0 + r, 0), h - 1);
-        const int gx = min(max(x0 + c, 0), w - 1);
-        dst[i] = (float)img[(size_t)gy * pitch + gx];
+        const uint8_t *rowp = img + (uint32_t)gy * pitch;
+        const int X0 = xa + 4 * d;
+        t.edge[i] = 0;
+        if (inside) {   // wave-uniform
+            t.v[i] = *reinterpret_cast<const uint32_t *>(rowp + X0);
+        } else {
+            const int Xl = min(max(X0, 0), (w - 1) & ~3);
+            t.v[i] = *reinterpret_cast<const uint32_t *>(rowp + Xl);
+            t.edge[i] = (uint32_t)rowp[0] | ((uint32_t)rowp[w - 1] << 8);
+        }
     }
 }
 
-template <int NSEG>
+template <int NL>
+__device__ __forceinline__ void tile_commit(const TileLoad<NL> &t, float *dst, int w, int x0, int n, int nd,
+                                            bool inside, int lane)
+{
+    const int xa = x0 & ~3;
+    const float inv_nd = 1.0f / (float)nd;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int idx = min(lane + 64 * i, n * nd - 1);
+        const uint32_t v = t.v[i];
+        uint32_t b0 = v & 0xffu, b1 = (v >> 8) & 0xffu, b2 = (v >> 16) & 0xffu, b3 = v >> 24;
+        if (!inside) {   // wave-uniform
+            const int r = (int)(((float)idx + 0.5f) * inv_nd);
+            const int X0 = xa + 4 * (idx - r * nd);
+            const uint32_t l = t.edge[i] & 0xffu, rr = t.edge[i] >> 8;
+            b0 = (X0 + 0 < 0) ? l : ((X0 + 0 >= w) ? rr : b0);
+            b1 = (X0 + 1 < 0) ? l : ((X0 + 1 >= w) ? rr : b1);
+            b2 = (X0 + 2 < 0) ? l : ((X0 + 2 >= w) ? rr : b2);
+            b3 = (X0 + 3 < 0) ? l : ((X0 + 3 >= w) ? rr : b3);
+        }
+        *reinterpret_cast<float4 *>(dst + 4 * idx) = make_float4((float)b0, (float)b1, (float)b2, (float)b3);
+    }
+}
+
+__device__ __forceinline__ bool tile_inside(int x0, int n, int nd, int w, uint32_t pitch)
+{
+    return x0 >= 0 && x0 + n <= w && (x0 & ~3) + 4 * nd <= (int)pitch;
+}
+
+// NSEG: max pixels per lane, WMAX: max window of this instantiation (bounds the unrolled staging)
+template <int NSEG, int WMAX>
 __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 {
+    constexpr int NLP = ((WMAX + 3) * ((WMAX + 9) / 4) + 63) / 64;
+    constexpr int NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * ((WMAX + 7 + 2 * LK_MARGIN) / 4) + 63) / 64;
+
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const uint32_t pi = blockIdx.x;
@@ -88,33 +159,37 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     if (pi >= n) return;
 
     float px, py, ex, ey;
-    KeypointF kp{};
     bool alive = true;
     if (a.item == kPoint2f) {
         const float2 p = reinterpret_cast<const float2 *>(a.prev_pts)[pi];
         const float2 e = reinterpret_cast<const float2 *>(a.estimates)[pi];
         px = p.x; py = p.y; ex = e.x; ey = e.y;
     } else {
-        kp = reinterpret_cast<const KeypointF *>(a.prev_pts)[pi];
+        const KeypointF *p = reinterpret_cast<const KeypointF *>(a.prev_pts) + pi;
         const KeypointF *e = reinterpret_cast<const KeypointF *>(a.estimates) + pi;
-        px = kp.x; py = kp.y; ex = e->x; ey = e->y;
-        alive = kp.tracking_status != 0;
+        px = p->x; py = p->y; ex = e->x; ey = e->y;
+        alive = p->tracking_status != 0;
     }
 
     const int w0 = (int)a.prev.width[0], h0 = (int)a.prev.height[0];
     bool ok = alive && px >= 0.0f && py >= 0.0f && px <= (float)(w0 - 1) && py <= (float)(h0 - 1);
 
     const int win = a.win, half = a.half;
-    const int PW = win + 3, GWD = win + 1, JW = win + 1 + 2 * LK_MARGIN;
-    float *P = smem;                 // (win+3)^2 template pixels (1-pixel margin for Scharr)
-    float *GX = P + PW * PW;         // (win+1)^2 Scharr x on the integer grid
-    float *GY = GX + GWD * GWD;
-    float *J = smem;                 // search tile; aliases P/GX/GY (dead once I/Ix/Iy are in registers)
+    const int PW = win + 3, JW = win + 1 + 2 * LK_MARGIN;
+    const int NDP = (PW + 6) >> 2, NDJ = (JW + 6) >> 2;
+    const int PS = 4 * NDP, JS = 4 * NDJ;     // LDS row strides (floats)
+    float *P = smem;                          // template tile; dead once I/Ix/Iy are in registers
+    float *J = smem;                          // search tile (aliases P)
 
-    const int row = lane / a.segs;
-    const int x0 = (lane - row * a.segs) * a.seglen;
-    int cnt = (lane < a.lanes) ? min(a.seglen, win - x0) : 0;
-    if (cnt < 0) cnt = 0;
+    // lane -> (window row, segment).  Idle lanes shadow lane 0 with cnt = 0: every lane runs the same
+    // branch-free code on valid LDS data and contributes exact zeros.
+    int row = lane / a.segs;
+    int x0 = (lane - row * a.segs) * a.seglen;
+    int cnt = min(a.seglen, win - x0);
+    if (lane >= a.lanes || cnt < 0) { row = 0; x0 = 0; cnt = 0; }
+
+    // LDS only ever holds converted pixels or these zeros, so over-reads past a segment are finite
+    for (int i = lane; i < a.lds_floats; i += 64) smem[i] = 0.0f;
 
     const int top = (int)a.prev.levels - 1;
     const float s_top = 1.0f / (float)(1u << top);
@@ -123,63 +198,89 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     const float inv_area = 1.0f / (float)(2 * win * win);
     const float fw = (float)win;
 
-    float Iw[NSEG], Ix[NSEG], Iy[NSEG];
+    float Iw[NSEG];
+    v2f Ig[NSEG];   // (Ix, Iy)
+
+    TileLoad<NLP> tp;
+    TileLoad<NLJ> tj;
+    int p_x0 = 0;
+    bool p_in = false;
+    if (ok) {   // template tile of the top level
+        p_x0 = (int)floorf(px * s_top) - half - 1;
+        const int p_y0 = (int)floorf(py * s_top) - half - 1;
+        p_in = tile_inside(p_x0, PW, NDP, (int)a.prev.width[top], a.prev.pitch[top]);
+        tile_issue(tp, a.prev.ptr[top], a.prev.pitch[top], (int)a.prev.width[top], (int)a.prev.height[top],
+                   p_x0, p_y0, PW, NDP, p_in, lane);
+    }
 
     for (int L = top; L >= 0 && ok; --L) {
-        const uint8_t *ip = a.prev.ptr[L];
-        const uint8_t *jp = a.curr.ptr[L];
-        const uint32_t ipitch = a.prev.pitch[L], jpitch = a.curr.pitch[L];
         const int lw = (int)a.prev.width[L], lh = (int)a.prev.height[L];
+        const uint8_t *jp = a.curr.ptr[L];
+        const uint32_t jpitch = a.curr.pitch[L];
         const float s = 1.0f / (float)(1u << L);
         const float ux = px * s, uy = py * s;
-        const float fx0 = floorf(ux), fy0 = floorf(uy);
-        const float ax = ux - fx0, ay = uy - fy0;
-        const int ix = (int)fx0 - half, iy = (int)fy0 - half;
+        const float ax = ux - floorf(ux), ay = uy - floorf(uy);
         vx = 0.0f; vy = 0.0f;
 
-        __syncthreads();  // previous level's search tile is dead
-        stage_tile(P, PW, ip, ipitch, lw, lh, ix - 1, iy - 1, lane);
-        __syncthreads();
-        {
-            const float inv = 1.0f / (float)GWD;
-            for (int i = lane; i < GWD * GWD; i += 64) {
-                const int r = (int)(((float)i + 0.5f) * inv);
-                const int c = i - r * GWD;
-                const float *q = P + (r + 1) * PW + (c + 1);
-                const float p00 = q[-PW - 1], p01 = q[-PW], p02 = q[-PW + 1];
-                const float p10 = q[-1], p12 = q[1];
-                const float p20 = q[PW - 1], p21 = q[PW], p22 = q[PW + 1];
-                GX[i] = (3.0f * (p02 - p00) + 10.0f * (p12 - p10)) + 3.0f * (p22 - p20);
-                GY[i] = (3.0f * (p20 - p00) + 10.0f * (p21 - p01)) + 3.0f * (p22 - p02);
-            }
-        }
+        // search tile around the prediction: its loads fly while the template is resampled
+        int jx0 = (int)floorf(ux + gx) - half - LK_MARGIN;
+        int jy0 = (int)floorf(uy + gy) - half - LK_MARGIN;
+        bool j_in = tile_inside(jx0, JW, NDJ, lw, jpitch);
+        tile_issue(tj, jp, jpitch, lw, lh, jx0, jy0, JW, NDJ, j_in, lane);
+
+        __syncthreads();   // previous level's search tile is dead
+        tile_commit(tp, P, lw, p_x0, PW, NDP, p_in, lane);
         __syncthreads();
 
+        // template pass: Scharr on the fly from four LDS rows (exact integers), bilinear resample
+        // of I, Ix, Iy into registers.  Streaming over the lane's P columns c = 0 .. cnt+2:
+        // grid column g = c-2 (centre P column c-1) completes at c, window pixel k = c-3 right after.
         float sxx = 0.0f, sxy = 0.0f, syy = 0.0f;
         {
-            const float *pt = P + (row + 1) * PW + (x0 + 1), *pb = pt + PW;
-            const float *xt = GX + row * GWD + x0, *xb = xt + GWD;
-            const float *yt = GY + row * GWD + x0, *yb = yt + GWD;
-            float a0 = 0, c0 = 0, xa = 0, xc = 0, ya = 0, yc = 0;
-            if (cnt > 0) { a0 = pt[0]; c0 = pb[0]; xa = xt[0]; xc = xb[0]; ya = yt[0]; yc = yb[0]; }
+            const float *q = P + row * PS + (p_x0 & 3) + x0;   // P(row + rr, x0 + c) = q[rr*PS + c]
+            v2f sm0 = splat(0.0f), sm1 = splat(0.0f), df0 = splat(0.0f), df1 = splat(0.0f), ctr1 = splat(0.0f);
+            v2f Ip = splat(0.0f), GXp = splat(0.0f), GYp = splat(0.0f);
 #pragma unroll
-            for (int k = 0; k < NSEG; ++k) {
-                Iw[k] = 0.0f; Ix[k] = 0.0f; Iy[k] = 0.0f;
-                if (k < cnt) {
-                    const float b0 = pt[k + 1], d0 = pb[k + 1];
-                    const float xb_ = xt[k + 1], xd = xb[k + 1];
-                    const float yb_ = yt[k + 1], yd = yb[k + 1];
-                    Iw[k] = bilerp(a0, b0, c0, d0, ax, ay);
-                    Ix[k] = bilerp(xa, xb_, xc, xd, ax, ay) * 0.03125f;
-                    Iy[k] = bilerp(ya, yb_, yc, yd, ax, ay) * 0.03125f;
-                    sxx = fmaf(Ix[k], Ix[k], sxx);
-                    sxy = fmaf(Ix[k], Iy[k], sxy);
-                    syy = fmaf(Iy[k], Iy[k], syy);
-                    a0 = b0; c0 = d0; xa = xb_; xc = xd; ya = yb_; yc = yd;
+            for (int c = 0; c < NSEG + 3; ++c) {
+                const float p0 = q[c], p1 = q[PS + c], p2 = q[2 * PS + c], p3 = q[3 * PS + c];
+                const v2f lo = { p0, p1 }, mid = { p1, p2 }, hi = { p2, p3 };      // (top, bottom) grid rows
+                const v2f sm = pk_fma(splat(3.0f), hi, pk_fma(splat(10.0f), mid, splat(3.0f) * lo));
+                const v2f df = hi - lo;
+                if (c >= 2) {
+                    const v2f Ic = ctr1;
+                    const v2f GXc = sm - sm0;
+                    const v2f GYc = pk_fma(splat(3.0f), df, pk_fma(splat(10.0f), df1, splat(3.0f) * df0));
+                    if (c >= 3) {
+                        const int k = c - 3;
+                        const v2f hi_ = pk_fma(splat(ax), Ic - Ip, Ip);          // (top, bot) horizontal lerps
+                        const v2f hx = pk_fma(splat(ax), GXc - GXp, GXp);
+                        const v2f hy = pk_fma(splat(ax), GYc - GYp, GYp);
+                        Iw[k] = fmaf(ay, hi_.y - hi_.x, hi_.x);
+                        const v2f tops = { hx.x, hy.x }, bots = { hx.y, hy.y };
+                        v2f g = pk_fma(splat(ay), bots - tops, tops) * splat(0.03125f);
+                        if (k >= cnt) g = splat(0.0f);                           // select, not a branch
+                        Ig[k] = g;
+                        sxx = fmaf(g.x, g.x, sxx);
+                        sxy = fmaf(g.x, g.y, sxy);
+                        syy = fmaf(g.y, g.y, syy);
+                    }
+                    Ip = Ic; GXp = GXc; GYp = GYc;
                 }
+                sm0 = sm1; sm1 = sm; df0 = df1; df1 = df; ctr1 = mid;
             }
         }
         const float Gxx = wave_sum(sxx), Gxy = wave_sum(sxy), Gyy = wave_sum(syy);
+
+        // next level's template loads fly while this level iterates
+        if (L > 0) {
+            const float sn = 1.0f / (float)(1u << (L - 1));
+            p_x0 = (int)floorf(px * sn) - half - 1;
+            const int p_y0 = (int)floorf(py * sn) - half - 1;
+            const int nw = (int)a.prev.width[L - 1];
+            p_in = tile_inside(p_x0, PW, NDP, nw, a.prev.pitch[L - 1]);
+            tile_issue(tp, a.prev.ptr[L - 1], a.prev.pitch[L - 1], nw, (int)a.prev.height[L - 1],
+                       p_x0, p_y0, PW, NDP, p_in, lane);
+        }
 
         const float det = Gxx * Gyy - Gxy * Gxy;
         const float dxy = Gxx - Gyy;
@@ -193,10 +294,9 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         const float inv_det = 1.0f / det;
         const float flw = (float)lw, flh = (float)lh;
 
-        // search tile around the prediction
-        int jx0 = (int)floorf(ux + gx) - half - LK_MARGIN;
-        int jy0 = (int)floorf(uy + gy) - half - LK_MARGIN;
-        bool staged = false;
+        __syncthreads();   // every lane is done with P
+        tile_commit(tj, J, lw, jx0, JW, NDJ, j_in, lane);
+        __syncthreads();
 
         for (uint32_t it = 0; it < a.max_it; ++it) {
             const float cx = (ux + gx) + vx, cy = (uy + gy) + vy;
@@ -205,31 +305,30 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             const float bx = cx - jfx, by = cy - jfy;
             const int jx = (int)jfx - half, jy = (int)jfy - half;
             int ox = jx - jx0, oy = jy - jy0;
-            if (!staged || ox < 0 || oy < 0 || ox > 2 * LK_MARGIN || oy > 2 * LK_MARGIN) {
-                if (staged) { jx0 = jx - LK_MARGIN; jy0 = jy - LK_MARGIN; ox = LK_MARGIN; oy = LK_MARGIN; }
+            if (ox < 0 || oy < 0 || ox > 2 * LK_MARGIN || oy > 2 * LK_MARGIN) {
+                // walked out of the staged tile: restage around the current position (rare)
+                jx0 = jx - LK_MARGIN; jy0 = jy - LK_MARGIN; ox = LK_MARGIN; oy = LK_MARGIN;
+                j_in = tile_inside(jx0, JW, NDJ, lw, jpitch);
+                tile_issue(tj, jp, jpitch, lw, lh, jx0, jy0, JW, NDJ, j_in, lane);
                 __syncthreads();
-                stage_tile(J, JW, jp, jpitch, lw, lh, jx0, jy0, lane);
+                tile_commit(tj, J, lw, jx0, JW, NDJ, j_in, lane);
                 __syncthreads();
-                staged = true;
             }
-            float s1 = 0.0f, s2 = 0.0f;
+            v2f acc = splat(0.0f);
             {
-                const float *jt = J + (oy + row) * JW + (ox + x0), *jb = jt + JW;
-                float a0 = 0, c0 = 0;
-                if (cnt > 0) { a0 = jt[0]; c0 = jb[0]; }
+                const float *jt = J + (oy + row) * JS + (jx0 & 3) + ox + x0;
+                v2f prev = { jt[0], jt[JS] };
 #pragma unroll
-                for (int k = 0; k < NSEG; ++k) {
-                    if (k < cnt) {
-                        const float b0 = jt[k + 1], d0 = jb[k + 1];
-                        const float jv = bilerp(a0, b0, c0, d0, bx, by);
-                        const float d = Iw[k] - jv;
-                        s1 = fmaf(d, Ix[k], s1);
-                        s2 = fmaf(d, Iy[k], s2);
-                        a0 = b0; c0 = d0;
-                    }
+                for (int k = 0; k < NSEG; ++k) {   // pixels past cnt have Ig = 0 and add exact zeros
+                    const v2f cur = { jt[k + 1], jt[JS + k + 1] };
+                    const v2f h = pk_fma(splat(bx), cur - prev, prev);
+                    const float jv = fmaf(by, h.y - h.x, h.x);
+                    const float d = Iw[k] - jv;
+                    acc = pk_fma(splat(d), Ig[k], acc);
+                    prev = cur;
                 }
             }
-            const float b1 = wave_sum(s1), b2 = wave_sum(s2);
+            const float b1 = wave_sum(acc.x), b2 = wave_sum(acc.y);
             const float etx = (Gyy * b1 - Gxy * b2) * inv_det;
             const float ety = (Gxx * b2 - Gxy * b1) * inv_det;
             vx += etx; vy += ety;
@@ -247,7 +346,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         if (a.item == kPoint2f) {
             reinterpret_cast<float2 *>(a.out)[pi] = ok ? make_float2(rx, ry) : make_float2(-1.0f, -1.0f);
         } else {
-            KeypointF o = kp;
+            KeypointF o = reinterpret_cast<const KeypointF *>(a.prev_pts)[pi];
             o.error = 0.0f;
             if (ok) { o.x = rx; o.y = ry; o.tracking_status = 255; }
             else    { o.x = ex; o.y = ey; o.tracking_status = 0; }
@@ -261,6 +360,11 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
 {
     if (p.capacity == 0) return hipSuccess;
+    for (uint32_t l = 0; l < p.prev.levels; ++l) {
+        const bool aligned = ((uintptr_t)p.prev.ptr[l] % 4u == 0) && (p.prev.pitch[l] % 4u == 0) &&
+                             ((uintptr_t)p.curr.ptr[l] % 4u == 0) && (p.curr.pitch[l] % 4u == 0);
+        if (!aligned) return launch_pyrlk_generic(p, stream);
+    }
     LKArgs a{};
     a.prev = p.prev; a.curr = p.curr; a.item = p.item;
     a.prev_pts = p.prev_pts; a.prev_count = p.prev_count; a.estimates = p.estimates;
@@ -275,15 +379,16 @@ hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
     a.segs = (win + a.seglen - 1) / a.seglen;
     a.lanes = a.segs * win;
 
-    const int PW = win + 3, GWD = win + 1, JW = win + 1 + 2 * LK_MARGIN;
-    const size_t fl = (size_t)PW * PW + 2 * (size_t)GWD * GWD;
-    const size_t jl = (size_t)JW * JW;
-    const size_t lds = (fl > jl ? fl : jl) * sizeof(float);
+    const int PW = win + 3, JW = win + 1 + 2 * LK_MARGIN;
+    const size_t fl = (size_t)PW * 4 * ((PW + 6) >> 2);
+    const size_t jl = (size_t)JW * 4 * ((JW + 6) >> 2);
+    a.lds_floats = (int)(fl > jl ? fl : jl) + 32;   // slack: a lane may read NSEG floats past its segment
+    const size_t lds = (size_t)a.lds_floats * sizeof(float);
     const dim3 grid(p.capacity), block(64);
-    if (a.seglen <= 2)       hipLaunchKernelGGL(k_pyrlk<2>,  grid, block, lds, stream, a);
-    else if (a.seglen <= 4)  hipLaunchKernelGGL(k_pyrlk<4>,  grid, block, lds, stream, a);
-    else if (a.seglen <= 7)  hipLaunchKernelGGL(k_pyrlk<7>,  grid, block, lds, stream, a);
-    else                     hipLaunchKernelGGL(k_pyrlk<16>, grid, block, lds, stream, a);
+    if (win <= 10)      hipLaunchKernelGGL((k_pyrlk<2, 10>),  grid, block, lds, stream, a);
+    else if (win <= 16) hipLaunchKernelGGL((k_pyrlk<4, 16>),  grid, block, lds, stream, a);
+    else if (win <= 21) hipLaunchKernelGGL((k_pyrlk<7, 21>),  grid, block, lds, stream, a);
+    else                hipLaunchKernelGGL((k_pyrlk<16, 32>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 

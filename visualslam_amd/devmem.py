@@ -50,8 +50,10 @@ def pyramid_dims(width, height, levels, scale=0.5):
 
 
 class DevicePyramid:
-    def __init__(self, width, height, levels, device="cuda:0"):
-        self.levels = [DeviceImage(w, h, device=device) for (w, h) in pyramid_dims(width, height, levels)]
+    def __init__(self, width, height, levels, device="cuda:0", pitch_pad=None):
+        """pitch_pad: if given, level pitch = width + pitch_pad (to exercise unaligned rows)"""
+        self.levels = [DeviceImage(w, h, device=device, pitch=(w + pitch_pad) if pitch_pad is not None else None)
+                       for (w, h) in pyramid_dims(width, height, levels)]
         self.desc = nvxcu.make_pyramid([l.desc for l in self.levels])
 
     def upload(self, arrays):

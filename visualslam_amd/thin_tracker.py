@@ -41,6 +41,7 @@ class ThinFeatureTracker:
         sz = size_fn(width, height, nvxcu.NVXCU_TYPE_POINT2F, p.array_capacity, p.detector_cell_size)
         self.keypoints_buf = Scratch(sz.dev_buf_size, device)
         self.num_corners = torch.zeros(1, dtype=torch.int64, device=device)
+        self.lk_events = None   # set to a list to collect (start, end) HIP event pairs around PyrLK
 
     def _check(self, st, what):
         if st != nvxcu.NVXCU_SUCCESS:
@@ -84,9 +85,15 @@ class ThinFeatureTracker:
             # initial estimate = previous positions (count + payload), :288-295
             self.kp_curr_list.count.copy_(self.prev_pts.count, non_blocking=True)
             self.kp_curr_list.buf.copy_(self.prev_pts.buf, non_blocking=True)
+            if self.lk_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
             st = nvxcu.optical_flow_pyr_lk(self.prev_pyr.desc, self.curr_pyr.desc, self.prev_pts.desc,
                                            self.kp_curr_list.desc, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 0.01,
                                            p.lk_num_iters, p.lk_win_size, self.target)
+            if self.lk_events is not None:
+                e1.record(self.stream)
+                self.lk_events.append((e0, e1))
             self._check(st, "optical flow")
             self._detect(self.kp_curr_list.desc)
 
