@@ -51,58 +51,128 @@ __global__ __launch_bounds__(256) void k_rgbx_to_u8_scalar(const uint8_t *__rest
     dst[(size_t)y * dp + x] = (uint8_t)((54u * s[0] + 183u * s[1] + 19u * s[2] + 128u) >> 8);
 }
 
-// ---- Gaussian HALF step ---------------------------------------------------------------------
-// One workgroup produces a 64x16 output tile from a (2*64+3)x(2*16+3) input tile staged in LDS:
-// separable [1 4 6 4 1] with the horizontal pass kept at full precision (<= 4080, u16), a single
-// rounding after the vertical pass.  Each lane of the vertical pass owns 4 adjacent outputs so
-// the store is one dword.
-constexpr int PT_W = 64, PT_H = 16;
-constexpr int PIN_W = 2 * PT_W + 3, PIN_H = 2 * PT_H + 3, PIN_STRIDE = 132;
+// ---- Gaussian pyramid, up to four HALF steps fused in one launch -----------------------------
+// One workgroup owns a TxT tile of the group's top level and builds everything under it in LDS:
+// the source region (side 2^NS*T + 3*(2^NS-1)) is fetched once as aligned dwords, then each step
+// runs the separable [1 4 6 4 1] filter LDS->LDS (horizontal pass kept at full precision in u16,
+// one rounding after the vertical pass) and stores the pixels the tile owns.  Regions carry
+// replicate semantics: the entry for an out-of-range coordinate holds the value at the clamped
+// coordinate, so every step is the oracle's clamp-at-each-level arithmetic.
+// For 1080p / 5 levels this is ONE launch of 510 workgroups instead of four dependent launches,
+// and level 0 is read from HBM once.
+constexpr int PYR_THREADS = 1024;   // 16 waves per workgroup: short per-thread loops, latency hidden by waves
+constexpr int pyr_region(int t, int up) { return up == 0 ? t : 2 * pyr_region(t, up - 1) + 3; }
 
-__global__ __launch_bounds__(256) void k_gaussian_half(const uint8_t *__restrict__ src, uint32_t sp,
-                                                       int sw, int sh,
-                                                       uint8_t *__restrict__ dst, uint32_t dp,
-                                                       int dw, int dh, int vec_store)
+struct PyrFusedArgs {
+    const uint8_t *src;
+    uint32_t src_pitch;
+    int sw, sh;
+    uint8_t *dst[4];
+    uint32_t dst_pitch[4];
+    int dw[4], dh[4];
+    int aligned;    // src base and pitch are multiples of 4
+};
+
+template <int RS, int SS, int RD>
+__device__ __forceinline__ void pyr_step(const uint8_t *src, int soff, int sox, int soy,
+                                         uint8_t *dstl, int dox, int doy, int dw, int dh,
+                                         uint16_t *tmp, uint8_t *gdst, uint32_t gpitch,
+                                         int own_x0, int own_y0, int own_n, int tid)
 {
-    __shared__ uint8_t tin[PIN_H][PIN_STRIDE];
-    __shared__ __attribute__((aligned(8))) uint16_t th[PIN_H][PT_W];
+    // horizontal: every source-region row, every destination column
+    for (int i = tid; i < RS * RD; i += PYR_THREADS) {
+        const int r = i / RD, c = i % RD;
+        const int xc = min(max(dox + c, 0), dw - 1);
+        const uint8_t *p = src + r * SS + soff + (2 * xc - 2 - sox);
+        tmp[i] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+    }
+    __syncthreads();
+    for (int i = tid; i < RD * RD; i += PYR_THREADS) {
+        const int y = i / RD, x = i % RD;
+        const int Y = doy + y, X = dox + x;
+        const int yc = min(max(Y, 0), dh - 1);
+        const uint16_t *t = tmp + (2 * yc - 2 - soy) * RD + x;
+        const uint32_t s = t[0] + 4u * t[RD] + 6u * t[2 * RD] + 4u * t[3 * RD] + t[4 * RD];
+        const uint8_t v = (uint8_t)((s + 128u) >> 8);
+        dstl[i] = v;
+        if (X >= own_x0 && X < own_x0 + own_n && Y >= own_y0 && Y < own_y0 + own_n && X < dw && Y < dh)
+            gdst[(size_t)Y * gpitch + X] = v;
+    }
+    __syncthreads();
+}
+
+template <int NS, int T>
+__global__ __launch_bounds__(PYR_THREADS) void k_pyramid_fused(PyrFusedArgs a)
+{
+    constexpr int R0 = pyr_region(T, NS);
+    constexpr int R1 = pyr_region(T, NS - 1);
+    constexpr int R2 = NS >= 2 ? pyr_region(T, NS - 2) : 1;
+    constexpr int R3 = NS >= 3 ? pyr_region(T, NS - 3) : 1;
+    constexpr int R4 = NS >= 4 ? pyr_region(T, NS - 4) : 1;
+    constexpr int S0 = (R0 + 3 + 3) / 4 * 4;          // aligned-dword row stride of the source region
+    constexpr int ND = S0 / 4;
+
+    __shared__ __attribute__((aligned(16))) uint8_t l0[R0 * S0];
+    __shared__ uint8_t l1[R1 * R1];
+    __shared__ uint8_t l2[R2 * R2];
+    __shared__ uint8_t l3[R3 * R3];
+    __shared__ uint8_t l4[R4 * R4];
+    __shared__ uint16_t tmp[R0 * R1];
 
     const int tid = threadIdx.x;
-    const int ox = blockIdx.x * PT_W, oy = blockIdx.y * PT_H;
-    const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
-
-    for (int i = tid; i < PIN_H * PIN_STRIDE; i += 256) {
-        const int r = i / PIN_STRIDE, c = i % PIN_STRIDE;
-        if (c < PIN_W) {
-            const int gy = min(max(sy0 + r, 0), sh - 1);
-            const int gx = min(max(sx0 + c, 0), sw - 1);
-            tin[r][c] = src[(size_t)gy * sp + gx];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < PIN_H * PT_W; i += 256) {
-        const int r = i / PT_W, x = i % PT_W;
-        const uint8_t *p = &tin[r][2 * x];
-        th[r][x] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
-    }
-    __syncthreads();
-
-    const int x4 = (tid & 15) * 4, y = tid >> 4;
-    const int gx = ox + x4, gy = oy + y;
-    if (gy >= dh || gx >= dw) return;
-    uint32_t o[4];
+    int ox[5], oy[5];
+    ox[NS] = blockIdx.x * T;
+    oy[NS] = blockIdx.y * T;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t s = th[2 * y][x4 + i] + 4u * th[2 * y + 1][x4 + i] + 6u * th[2 * y + 2][x4 + i] +
-                           4u * th[2 * y + 3][x4 + i] + th[2 * y + 4][x4 + i];
-        o[i] = (s + 128u) >> 8;
-    }
-    uint8_t *d = dst + (size_t)gy * dp + gx;
-    if (vec_store && gx + 4 <= dw) {
-        *reinterpret_cast<uint32_t *>(d) = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+    for (int g = NS; g > 0; --g) { ox[g - 1] = 2 * ox[g] - 2; oy[g - 1] = 2 * oy[g] - 2; }
+
+    // source region
+    const int xa = ox[0] & ~3, off = ox[0] - xa;
+    if (a.aligned) {
+        uint32_t *l0w = reinterpret_cast<uint32_t *>(l0);
+        const int xmax = (a.sw - 1) & ~3;
+        constexpr int NLD = (R0 * ND + PYR_THREADS - 1) / PYR_THREADS;
+        uint32_t v[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {   // all loads in flight before the first LDS write
+            const int i = min(tid + k * PYR_THREADS, R0 * ND - 1);
+            const int r = i / ND, d = i % ND;
+            const int gy = min(max(oy[0] + r, 0), a.sh - 1);
+            const int X = min(max(xa + 4 * d, 0), xmax);
+            v[k] = *reinterpret_cast<const uint32_t *>(a.src + (size_t)gy * a.src_pitch + X);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) l0w[min(tid + k * PYR_THREADS, R0 * ND - 1)] = v[k];
+        __syncthreads();
+        if (ox[0] < 0 || ox[0] + R0 > a.sw) {   // replicate the columns outside the image
+            for (int i = tid; i < R0 * R0; i += PYR_THREADS) {
+                const int r = i / R0, c = i % R0;
+                const int X = ox[0] + c;
+                if (X < 0 || X >= a.sw) l0[r * S0 + off + c] = l0[r * S0 + (min(max(X, 0), a.sw - 1) - xa)];
+            }
+            __syncthreads();
+        }
     } else {
-        for (int i = 0; i < 4 && gx + i < dw; ++i) d[i] = (uint8_t)o[i];
+        for (int i = tid; i < R0 * R0; i += PYR_THREADS) {
+            const int r = i / R0, c = i % R0;
+            const int gy = min(max(oy[0] + r, 0), a.sh - 1);
+            const int gx = min(max(ox[0] + c, 0), a.sw - 1);
+            l0[r * S0 + off + c] = a.src[(size_t)gy * a.src_pitch + gx];
+        }
+        __syncthreads();
     }
+
+    pyr_step<R0, S0, R1>(l0, off, ox[0], oy[0], l1, ox[1], oy[1], a.dw[0], a.dh[0], tmp, a.dst[0], a.dst_pitch[0],
+                         ox[NS] << (NS - 1), oy[NS] << (NS - 1), T << (NS - 1), tid);
+    if (NS >= 2)
+        pyr_step<R1, R1, R2>(l1, 0, ox[1], oy[1], l2, ox[2], oy[2], a.dw[1], a.dh[1], tmp, a.dst[1], a.dst_pitch[1],
+                             ox[NS] << (NS - 2), oy[NS] << (NS - 2), T << (NS - 2), tid);
+    if (NS >= 3)
+        pyr_step<R2, R2, R3>(l2, 0, ox[2], oy[2], l3, ox[3], oy[3], a.dw[2], a.dh[2], tmp, a.dst[2], a.dst_pitch[2],
+                             ox[NS] << (NS - 3), oy[NS] << (NS - 3), T << (NS - 3), tid);
+    if (NS >= 4)
+        pyr_step<R3, R3, R4>(l3, 0, ox[3], oy[3], l4, ox[4], oy[4], a.dw[3], a.dh[3], tmp, a.dst[3], a.dst_pitch[3],
+                             ox[NS], oy[NS], T, tid);
 }
 
 }  // namespace
@@ -125,15 +195,33 @@ hipError_t launch_rgbx_to_u8(const ImageView &src, uint8_t *dst, uint32_t dst_pi
     return hipGetLastError();
 }
 
-hipError_t launch_gaussian_half(const ImageView &src, uint8_t *dst, uint32_t dst_pitch,
-                                uint32_t dst_width, uint32_t dst_height, hipStream_t stream)
+hipError_t launch_gaussian_pyramid(const PyramidView &pyr, hipStream_t stream)
 {
-    if (dst_width == 0 || dst_height == 0) return hipSuccess;
-    const int vec = ((uintptr_t)dst % 4u == 0) && (dst_pitch % 4u == 0);
-    const dim3 grid((dst_width + PT_W - 1) / PT_W, (dst_height + PT_H - 1) / PT_H);
-    hipLaunchKernelGGL(k_gaussian_half, grid, dim3(256), 0, stream, src.ptr, src.pitch, (int)src.width,
-                       (int)src.height, dst, dst_pitch, (int)dst_width, (int)dst_height, vec);
-    return hipGetLastError();
+    uint32_t lvl = 0;
+    while (lvl + 1 < pyr.levels) {
+        const uint32_t ns = (pyr.levels - 1 - lvl) < 4u ? (pyr.levels - 1 - lvl) : 4u;
+        PyrFusedArgs a{};
+        a.src = pyr.ptr[lvl]; a.src_pitch = pyr.pitch[lvl];
+        a.sw = (int)pyr.width[lvl]; a.sh = (int)pyr.height[lvl];
+        a.aligned = ((uintptr_t)a.src % 4u == 0) && (a.src_pitch % 4u == 0);
+        for (uint32_t g = 0; g < ns; ++g) {
+            a.dst[g] = const_cast<uint8_t *>(pyr.ptr[lvl + 1 + g]);
+            a.dst_pitch[g] = pyr.pitch[lvl + 1 + g];
+            a.dw[g] = (int)pyr.width[lvl + 1 + g];
+            a.dh[g] = (int)pyr.height[lvl + 1 + g];
+        }
+        const int tw = a.dw[ns - 1], th = a.dh[ns - 1];
+        switch (ns) {
+        case 1: hipLaunchKernelGGL((k_pyramid_fused<1, 32>), dim3((tw + 31) / 32, (th + 31) / 32), dim3(PYR_THREADS), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((k_pyramid_fused<2, 16>), dim3((tw + 15) / 16, (th + 15) / 16), dim3(PYR_THREADS), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((k_pyramid_fused<3, 8>), dim3((tw + 7) / 8, (th + 7) / 8), dim3(PYR_THREADS), 0, stream, a); break;
+        default: hipLaunchKernelGGL((k_pyramid_fused<4, 4>), dim3((tw + 3) / 4, (th + 3) / 4), dim3(PYR_THREADS), 0, stream, a); break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        lvl += ns;
+    }
+    return hipSuccess;
 }
 
 }  // namespace vsa

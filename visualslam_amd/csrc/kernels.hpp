@@ -34,9 +34,9 @@ struct PyramidView {
 // RGBX -> U8 luma, (54 R + 183 G + 19 B + 128) >> 8
 hipError_t launch_rgbx_to_u8(const ImageView &src, uint8_t *dst, uint32_t dst_pitch, hipStream_t stream);
 
-// dst(x,y) = (sum_{i,j} w_i w_j src(clamp(2x+i-2), clamp(2y+j-2)) + 128) >> 8, w = [1 4 6 4 1]
-hipError_t launch_gaussian_half(const ImageView &src, uint8_t *dst, uint32_t dst_pitch,
-                                uint32_t dst_width, uint32_t dst_height, hipStream_t stream);
+// levels 1..n-1 from level 0: dst(x,y) = (sum_{i,j} w_i w_j src(clamp(2x+i-2), clamp(2y+j-2)) + 128) >> 8,
+// w = [1 4 6 4 1]; up to four steps fused per launch
+hipError_t launch_gaussian_pyramid(const PyramidView &pyr, hipStream_t stream);
 
 struct CornerTrackParams {
     Detector detector;

@@ -169,13 +169,7 @@ nvxcu_error_status_e nvxcuGaussianPyramid(const nvxcu_pyramid_t *pyramid, const 
     PyramidView v{};
     nvxcu_error_status_e st = pyramid_view(pyramid, &v);
     if (st != NVXCU_SUCCESS) return st;
-    for (uint32_t i = 1; i < v.levels; ++i) {
-        const ImageView src{ v.ptr[i - 1], v.pitch[i - 1], v.width[i - 1], v.height[i - 1] };
-        hipError_t e = launch_gaussian_half(src, const_cast<uint8_t *>(v.ptr[i]), v.pitch[i], v.width[i],
-                                            v.height[i], stream);
-        if (e != hipSuccess) return NVXCU_FAILURE;
-    }
-    return NVXCU_SUCCESS;
+    return from_hip(launch_gaussian_pyramid(v, stream));
 }
 
 nvxcu_tmp_buf_size_t nvxcuHarrisTrack_GetBufSize(uint32_t width, uint32_t height, nvxcu_df_image_e,
