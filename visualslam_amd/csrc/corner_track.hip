@@ -4,7 +4,7 @@
 // Reference call sites replaced: nvxHarrisTrackNode / nvxcuHarrisTrack and nvxFastTrackNode /
 // nvxcuFastTrack (demos/feature_tracker/feature_tracker.cpp:418-430,
 // demos/feature_tracker_nvxcu/feature_tracker_nvxcu.cpp:307-317).  Semantics: oracle/vxoracle.c
-// (select_and_merge, orc_harris_response, orc_fast_strength).
+// (cell selection/merge, Harris response and FAST strength functions).
 //
 // Two launches, no atomics on global memory, no host round trip:
 //   k_corner_cells<DET>  one workgroup OWNS a rectangle of whole detector cells; it walks that
