@@ -1,0 +1,300 @@
+"""GPU tests of the OpenVX node/graph C API (VX/vx.h, NVX/nvx.h): the feature_tracker graph built and
+driven exactly as demos/feature_tracker/feature_tracker.cpp does, compared frame by frame with the
+oracle; the reference's own wrapper (compiled unmodified into oracle/_ref/ft_headless) run end to end;
+data access, performance counters and asynchronous graphs."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O
+from oracle.pipeline import OracleTracker
+from visualslam_amd import ovx, synth
+from visualslam_amd.thin_tracker import Params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = ovx.lib()
+
+
+@pytest.fixture
+def ctx(gpu):
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    yield c
+    h = C.c_void_p(c)
+    assert L.vxReleaseContext(C.byref(h)) == ovx.VX_SUCCESS
+
+
+class VxFeatureTracker:
+    """call-for-call transcription of FeatureTrackerImpl (feature_tracker.cpp:127-449)"""
+
+    def __init__(self, ctx, p, w, h, first_frame, mask):
+        self.ctx, self.p = ctx, p
+        pex = L.vxCreatePyramid(ctx, p.pyr_levels, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
+        self.pyr_delay = L.vxCreateDelay(ctx, pex, 2)
+        ovx.release("Pyramid", pex)
+        aex = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, p.array_capacity)
+        self.pts_delay = L.vxCreateDelay(ctx, aex, 2)
+        ovx.release("Array", aex)
+        self.kp_curr = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, p.array_capacity)
+        # createMainGraph
+        self.g = L.vxCreateGraph(ctx)
+        pyr0 = L.vxGetReferenceFromDelay(self.pyr_delay, 0)
+        gray = L.vxGetPyramidLevel(pyr0, 0)
+        eps, it, est = ovx.scalar(ctx, ovx.VX_TYPE_FLOAT32, 0.01), ovx.scalar(ctx, ovx.VX_TYPE_UINT32, p.lk_num_iters), ovx.scalar(ctx, ovx.VX_TYPE_BOOL, 0)
+        self.cvt = L.vxColorConvertNode(self.g, first_frame, gray)
+        self.pyr = L.vxGaussianPyramidNode(self.g, gray, pyr0)
+        self.lk = L.vxOpticalFlowPyrLKNode(self.g, L.vxGetReferenceFromDelay(self.pyr_delay, -1), pyr0,
+                                           L.vxGetReferenceFromDelay(self.pts_delay, -1), L.vxGetReferenceFromDelay(self.pts_delay, -1),
+                                           self.kp_curr, ovx.VX_TERM_CRITERIA_BOTH, eps, it, est, p.lk_win_size)
+        out = L.vxGetReferenceFromDelay(self.pts_delay, 0)
+        if p.use_harris_detector:
+            self.det = L.nvxHarrisTrackNode(self.g, gray, out, mask, self.kp_curr, p.harris_k, p.harris_thresh, p.detector_cell_size, None)
+        else:
+            self.det = L.nvxFastTrackNode(self.g, gray, out, mask, self.kp_curr, p.fast_type, p.fast_thresh, p.detector_cell_size, None)
+        for n in (self.cvt, self.pyr, self.lk, self.det):
+            assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+        opt = b"-O3"
+        ovx.check(L.vxSetGraphAttribute(self.g, ovx.NVX_GRAPH_VERIFY_OPTIONS, opt, len(opt)))
+        ovx.check(L.vxVerifyGraph(self.g), "vxVerifyGraph")
+        for s in (eps, it, est):
+            ovx.release("Scalar", s)
+        ovx.release("Image", gray)
+        # processFirstFrame
+        w_, h_ = w, h
+        fgray = L.vxCreateImage(ctx, w_, h_, ovx.VX_DF_IMAGE_U8)
+        ovx.check(L.vxuColorConvert(ctx, first_frame, fgray), "vxuColorConvert")
+        ovx.check(L.vxuGaussianPyramid(ctx, fgray, L.vxGetReferenceFromDelay(self.pyr_delay, 0)), "vxuGaussianPyramid")
+        if p.use_harris_detector:
+            ovx.check(L.nvxuHarrisTrack(ctx, fgray, L.vxGetReferenceFromDelay(self.pts_delay, 0), mask, None,
+                                        p.harris_k, p.harris_thresh, p.detector_cell_size, None), "nvxuHarrisTrack")
+        else:
+            ovx.check(L.nvxuFastTrack(ctx, fgray, L.vxGetReferenceFromDelay(self.pts_delay, 0), mask, None,
+                                      p.fast_type, p.fast_thresh, p.detector_cell_size, None), "nvxuFastTrack")
+        ovx.release("Image", fgray)
+
+    def track(self, frame, mask, schedule_only=False):
+        ovx.check(L.vxSetParameterByIndex(self.cvt, 0, frame))
+        ovx.check(L.vxSetParameterByIndex(self.det, 2, mask))
+        ovx.check(L.vxAgeDelay(self.pyr_delay))
+        ovx.check(L.vxAgeDelay(self.pts_delay))
+        if schedule_only:
+            ovx.check(L.vxScheduleGraph(self.g), "vxScheduleGraph")
+        else:
+            ovx.check(L.vxProcessGraph(self.g), "vxProcessGraph")
+
+    def prev(self):
+        return ovx.read_array(L.vxGetReferenceFromDelay(self.pts_delay, -1))
+
+    def curr(self):
+        return ovx.read_array(self.kp_curr)
+
+    def merged(self):
+        return ovx.read_array(L.vxGetReferenceFromDelay(self.pts_delay, 0))
+
+
+def _frames(w, h, n, seed):
+    base = synth.base_frame(w, h, seed)
+    return [synth.to_rgbx(synth.gray_frame(base, t, seed)) for t in range(n)]
+
+
+@pytest.mark.parametrize("harris,win,levels,use_mask", [(True, 6, 6, False), (False, 10, 4, True), (True, 21, 5, True)])
+def test_feature_tracker_graph_matches_oracle(ctx, harris, win, levels, use_mask):
+    w, h, n = 640, 480, 6
+    p = Params(pyr_levels=levels, lk_win_size=win, use_harris_detector=harris, harris_thresh=2000.0)
+    frames = _frames(w, h, n, seed=7 + win)
+    mask_np = None
+    mask = None
+    if use_mask:
+        mask_np = np.full((h, w), 255, np.uint8)
+        mask_np[:, w // 2:] = 0
+        mask = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
+        ovx.write_image(mask, mask_np)
+    # main_feature_tracker.cpp:233-246: a 2-slot delay of RGBX frames; handles stay bound to their index
+    ex = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+    frame_delay = L.vxCreateDelay(ctx, ex, 2)
+    ovx.release("Image", ex)
+    frame, prev_frame = L.vxGetReferenceFromDelay(frame_delay, 0), L.vxGetReferenceFromDelay(frame_delay, -1)
+
+    ovx.write_image(frame, frames[0])
+    trk = VxFeatureTracker(ctx, p, w, h, frame, mask)
+    ref = OracleTracker(p)
+    ref.init(frames[0], mask_np)
+    np.testing.assert_array_equal(trk.merged(), ref.prev_pts)
+    ovx.check(L.vxAgeDelay(frame_delay))
+    for t in range(1, n):
+        ovx.write_image(frame, frames[t])
+        trk.track(frame, mask)
+        old, cur = ref.track(frames[t], mask_np)
+        np.testing.assert_array_equal(trk.prev(), old, err_msg=f"frame {t}: previous features")
+        got = trk.curr()
+        assert got.shape == cur.shape                                               # same count, same order
+        np.testing.assert_array_equal(got[:, 0] >= 0, cur[:, 0] >= 0)               # status flags
+        assert np.abs(got - cur).max() <= 0.01 and got.tobytes() == cur.tobytes()
+        np.testing.assert_array_equal(trk.merged(), ref.prev_pts, err_msg=f"frame {t}: merged features")
+        np.testing.assert_array_equal(ovx.read_image(prev_frame), frames[t - 1])    # aged data sits at index -1
+        ovx.check(L.vxAgeDelay(frame_delay))
+        assert (cur[:, 0] >= 0).mean() > 0.8
+
+
+def test_reference_wrapper_compiled_unmodified_runs(gpu, tmp_path):
+    """oracle/_ref/ft_headless = the reference's demos/feature_tracker/feature_tracker.cpp compiled
+    unmodified (oracle/Makefile.ref) + our headless driver, linked against libvisualslam_amd."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ft_headless")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ft_headless not built (needs /root/reference at build time)")
+    w, h, n = 640, 480, 8
+    frames = _frames(w, h, n, seed=23)
+    fpath, opath = tmp_path / "frames.rgbx", tmp_path / "out.bin"
+    with open(fpath, "wb") as f:
+        for fr in frames:
+            f.write(fr.tobytes())
+    # data/feature_tracker_demo_config.ini values
+    cfg = dict(pyr_levels=6, lk_num_iters=5, lk_win_size=6, array_capacity=2000, detector_cell_size=18,
+               detector="harris", harris_k=0.04, harris_thresh=2000.0)
+    cmd = [exe, str(fpath), str(w), str(h), str(n), str(opath)] + [f"{k}={v}" for k, v in cfg.items()]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "Found" in res.stdout                                   # FeatureTrackerImpl::printPerfs ran
+    p = Params(pyr_levels=6, lk_num_iters=5, lk_win_size=6, array_capacity=2000, harris_thresh=2000.0)
+    ref = OracleTracker(p)
+    ref.init(frames[0])
+    raw = np.fromfile(opath, np.uint8)
+    off = 0
+    for t in range(1, n):
+        old, cur = ref.track(frames[t])
+        for want in (old, cur):
+            cnt = int(raw[off:off + 4].view(np.uint32)[0]); off += 4
+            got = raw[off:off + 8 * cnt].view(np.float32).reshape(cnt, 2); off += 8 * cnt
+            assert cnt == len(want)
+            assert got.tobytes() == want.tobytes(), f"frame {t}"
+    assert off == raw.size
+
+
+def test_map_unmap_and_device_pointers(ctx):
+    import torch
+    w, h = 200, 100
+    img = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
+    data = np.random.default_rng(1).integers(0, 256, (h, w), dtype=np.uint8)
+    ovx.write_image(img, data)
+    rect = ovx.vx_rectangle_t(10, 20, 110, 70)
+    mid, addr, ptr = C.c_size_t(), ovx.vx_imagepatch_addressing_t(), C.c_void_p()
+    ovx.check(L.vxMapImagePatch(img, C.byref(rect), 0, C.byref(mid), C.byref(addr), C.byref(ptr), ovx.VX_READ_AND_WRITE, ovx.VX_MEMORY_TYPE_HOST, 0))
+    assert (addr.dim_x, addr.dim_y, addr.stride_x, addr.stride_y) == (100, 50, 1, 100)
+    view = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(50, 100))
+    np.testing.assert_array_equal(view, data[20:70, 10:110])
+    view[:] = 255 - view
+    ovx.check(L.vxUnmapImagePatch(img, mid))
+    want = data.copy()
+    want[20:70, 10:110] = 255 - want[20:70, 10:110]
+    np.testing.assert_array_equal(ovx.read_image(img), want)
+    # device pointer mapping (the reference's NVX_MEMORY_TYPE_CUDA, nvxio/src/OVX/Private/TypesOVX.cpp:58-64)
+    ovx.check(L.vxMapImagePatch(img, None, 0, C.byref(mid), C.byref(addr), C.byref(ptr), ovx.VX_READ_ONLY, ovx.NVX_MEMORY_TYPE_HIP, 0))
+    assert addr.stride_y >= w and addr.stride_y % 256 == 0
+    dev = torch.empty((h, addr.stride_y), dtype=torch.uint8, device="cuda:0")
+    from visualslam_amd import nvxcu
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(dev.data_ptr(), ptr, h * addr.stride_y, 3) == 0
+    np.testing.assert_array_equal(dev[:, :w].cpu().numpy(), want)
+    ovx.check(L.vxUnmapImagePatch(img, mid))
+    assert L.vxUnmapImagePatch(img, mid) == ovx.VX_ERROR_INVALID_PARAMETERS
+    # arrays: add / truncate / map / access-commit
+    arr = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 8)
+    pts = np.arange(10, dtype=np.float32).reshape(5, 2)
+    ovx.add_items(arr, pts)
+    assert ovx.num_items(arr) == 5
+    np.testing.assert_array_equal(ovx.read_array(arr), pts)
+    assert L.vxAddArrayItems(arr, 4, pts.ctypes.data, 8) == ovx.VX_FAILURE          # over capacity
+    ovx.check(L.vxTruncateArray(arr, 3))
+    assert ovx.num_items(arr) == 3
+    stride, aptr = C.c_size_t(), C.c_void_p()
+    ovx.check(L.vxAccessArrayRange(arr, 0, 3, C.byref(stride), C.byref(aptr), ovx.VX_READ_AND_WRITE))
+    v = np.ctypeslib.as_array(C.cast(aptr, C.POINTER(C.c_float)), shape=(3, 2))
+    v += 100
+    ovx.check(L.vxCommitArrayRange(arr, 0, 3, aptr))
+    np.testing.assert_array_equal(ovx.read_array(arr), pts[:3] + 100)
+
+
+def test_perf_counters_num_corners_and_async_graphs(ctx):
+    w, h = 640, 480
+    ovx.check(L.vxDirective(ctx, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
+    frames = _frames(w, h, 3, seed=3)
+    p = Params(pyr_levels=4, lk_win_size=10)
+    trackers, refs, imgs = [], [], []
+    for s in range(2):                                     # two independent camera streams in one context
+        img = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+        ovx.write_image(img, frames[s])
+        trackers.append(VxFeatureTracker(ctx, p, w, h, img, None))
+        r = OracleTracker(p)
+        r.init(frames[s])
+        refs.append(r)
+        imgs.append(img)
+    for s in range(2):
+        ovx.write_image(imgs[s], frames[s + 1])
+    for s in range(2):
+        trackers[s].track(imgs[s], None, schedule_only=True)          # both graphs in flight on their own streams
+    assert L.vxScheduleGraph(trackers[0].g) != ovx.VX_SUCCESS         # already scheduled
+    for s in range(2):
+        ovx.check(L.vxWaitGraph(trackers[s].g), "vxWaitGraph")
+        old, cur = refs[s].track(frames[s + 1])
+        assert trackers[s].curr().tobytes() == cur.tobytes()
+        np.testing.assert_array_equal(trackers[s].merged(), refs[s].prev_pts)
+    gp = ovx.query("vxQueryGraph", trackers[0].g, ovx.VX_GRAPH_PERFORMANCE, ovx.vx_perf_t)
+    assert gp.num == 1 and gp.tmp > 0 and gp.tmp == gp.sum == gp.min == gp.max
+    for node in (trackers[0].cvt, trackers[0].pyr, trackers[0].lk, trackers[0].det):
+        np_ = ovx.query("vxQueryNode", node, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
+        assert np_.num == 1 and 0 < np_.tmp < 50_000_000               # ns (UtilityOVX.cpp:46-68 divides by 1e6 for ms)
+    # num_corners scalar (VX_TYPE_SIZE) through the immediate call
+    gray = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
+    ovx.check(L.vxuColorConvert(ctx, imgs[0], gray))
+    out = L.vxCreateArray(ctx, ovx.NVX_TYPE_KEYPOINTF, 100)
+    nc = ovx.scalar(ctx, ovx.VX_TYPE_SIZE, 0)
+    ovx.check(L.nvxuHarrisTrack(ctx, gray, out, None, None, 0.04, 100.0, 18, nc))
+    total = C.c_size_t()
+    ovx.check(L.vxReadScalarValue(nc, C.byref(total)))
+    want, wtot, _ = O.harris_track(O.color_convert(frames[1]), None, None, 0.04, 100.0, 18, 100, item_type=O.KEYPOINTF)
+    assert total.value == wtot > 100 and ovx.num_items(out) == 100
+    assert ovx.read_array(out, O.keypointf_dtype).tobytes() == want.tobytes()
+
+
+def test_immediate_pyrlk_with_estimates_keypointf(ctx):
+    w, h, levels = 320, 240, 3
+    base = synth.base_frame(w, h, 12)
+    f0 = np.clip(np.rint(base), 0, 255).astype(np.uint8)
+    f1 = np.clip(np.rint(synth.shift_bilinear(base, 6.0, 2.5)), 0, 255).astype(np.uint8)
+    pyrs = []
+    for f in (f0, f1):
+        img = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
+        ovx.write_image(img, f)
+        pyr = L.vxCreatePyramid(ctx, levels, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
+        ovx.check(L.vxuGaussianPyramid(ctx, img, pyr))               # input is NOT level 0 here: it is copied in
+        pyrs.append(pyr)
+        lv0 = L.vxGetPyramidLevel(pyr, 0)
+        np.testing.assert_array_equal(ovx.read_image(lv0), f)
+        ovx.release("Image", lv0)
+    rng = np.random.default_rng(4)
+    kp = np.zeros(300, O.keypointf_dtype)
+    kp["x"], kp["y"] = rng.uniform(0, w - 1, 300), rng.uniform(0, h - 1, 300)
+    kp["strength"], kp["tracking_status"] = rng.uniform(1, 9, 300), rng.choice([0, 255], 300)
+    est = kp.copy()
+    est["x"] += 5
+    est["y"] += 2
+    arrs = []
+    for items in (kp, est):
+        a = L.vxCreateArray(ctx, ovx.NVX_TYPE_KEYPOINTF, 300)
+        ovx.add_items(a, items)
+        arrs.append(a)
+    out = L.vxCreateArray(ctx, ovx.NVX_TYPE_KEYPOINTF, 300)
+    eps, it = ovx.scalar(ctx, ovx.VX_TYPE_FLOAT32, 0.01), ovx.scalar(ctx, ovx.VX_TYPE_UINT32, 5)
+    p0, p1 = O.gaussian_pyramid(f0, levels), O.gaussian_pyramid(f1, levels)
+    for flag, e in ((1, est), (0, None)):
+        use = ovx.scalar(ctx, ovx.VX_TYPE_BOOL, flag)
+        ovx.check(L.vxuOpticalFlowPyrLK(ctx, pyrs[0], pyrs[1], arrs[0], arrs[1], out, ovx.VX_TERM_CRITERIA_BOTH, eps, it, use, 10))
+        want = O.optical_flow_pyr_lk(p0, p1, kp, e, O.TERM_BOTH, 0.01, 5, 10, item_type=O.KEYPOINTF)
+        assert ovx.num_items(out) == 300
+        assert ovx.read_array(out, O.keypointf_dtype).tobytes() == want.tobytes()

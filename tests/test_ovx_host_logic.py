@@ -1,0 +1,277 @@
+"""CPU tests of the OpenVX-subset runtime's host logic (object model, delays, verification order,
+error behaviour) through the C ABI.  No GPU here: the context is created in the runtime's
+host-logic-only mode (VISUALSLAM_AMD_ALLOW_NO_GPU=1), where objects exist but nothing can execute --
+vxProcessGraph and every vxu/nvxu call fail with NVX_ERROR_NO_GPU (there is no CPU fallback).
+Contract under test: SURVEY.md section 8b (ownership, errors, delay semantics)."""
+import ctypes as C
+import os
+
+import pytest
+
+from visualslam_amd import ovx
+
+L = ovx.lib()
+
+
+@pytest.fixture
+def ctx(monkeypatch):
+    monkeypatch.setenv("VISUALSLAM_AMD_ALLOW_NO_GPU", "1")
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    yield c
+    h = C.c_void_p(c)
+    assert L.vxReleaseContext(C.byref(h)) == ovx.VX_SUCCESS and h.value is None
+
+
+def test_context_without_gpu_reports_no_gpu(monkeypatch):
+    """nvxio/src/OVX/UtilityOVX.cpp:88-102: a GPU-less context is an object whose status says so"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    monkeypatch.delenv("VISUALSLAM_AMD_ALLOW_NO_GPU", raising=False)
+    c = L.vxCreateContext()
+    assert c and L.vxGetStatus(c) == ovx.NVX_ERROR_NO_GPU
+    img = L.vxCreateImage(c, 8, 8, ovx.VX_DF_IMAGE_U8)
+    assert img and L.vxGetStatus(img) == ovx.NVX_ERROR_NO_GPU      # error object, never NULL
+    h = C.c_void_p(c)
+    assert L.vxReleaseContext(C.byref(h)) == ovx.VX_SUCCESS
+
+
+def test_nothing_executes_without_gpu(ctx):
+    img = L.vxCreateImage(ctx, 32, 32, ovx.VX_DF_IMAGE_RGBX)
+    gray = L.vxCreateImage(ctx, 32, 32, ovx.VX_DF_IMAGE_U8)
+    assert L.vxuColorConvert(ctx, img, gray) == ovx.NVX_ERROR_NO_GPU
+    g = L.vxCreateGraph(ctx)
+    n = L.vxColorConvertNode(g, img, gray)
+    assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    assert L.vxProcessGraph(g) == ovx.NVX_ERROR_NO_GPU
+
+
+def test_create_query_release(ctx):
+    img = L.vxCreateImage(ctx, 640, 480, ovx.VX_DF_IMAGE_RGBX)
+    assert ovx.query("vxQueryImage", img, ovx.VX_IMAGE_WIDTH, C.c_uint32) == 640
+    assert ovx.query("vxQueryImage", img, ovx.VX_IMAGE_HEIGHT, C.c_uint32) == 480
+    assert ovx.query("vxQueryImage", img, ovx.VX_IMAGE_FORMAT, C.c_uint32) == ovx.VX_DF_IMAGE_RGBX
+    assert ovx.query("vxQueryImage", img, ovx.VX_IMAGE_PLANES, C.c_size_t) == 1
+    w = C.c_uint16()
+    assert L.vxQueryImage(img, ovx.VX_IMAGE_WIDTH, C.byref(w), 2) == ovx.VX_ERROR_INVALID_PARAMETERS   # wrong size
+    arr = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 2000)
+    assert ovx.query("vxQueryArray", arr, ovx.VX_ARRAY_CAPACITY, C.c_size_t) == 2000
+    assert ovx.query("vxQueryArray", arr, ovx.VX_ARRAY_ITEMSIZE, C.c_size_t) == 8
+    assert ovx.query("vxQueryArray", arr, ovx.VX_ARRAY_ITEMTYPE, C.c_int32) == ovx.NVX_TYPE_POINT2F
+    assert ovx.num_items(arr) == 0
+    kp = L.vxCreateArray(ctx, ovx.NVX_TYPE_KEYPOINTF, 10)
+    assert ovx.query("vxQueryArray", kp, ovx.VX_ARRAY_ITEMSIZE, C.c_size_t) == 28
+    assert L.vxGetContext(img) == ctx
+    # release sets the handle to NULL; releasing NULL is harmless (feature_tracker.cpp:254-270)
+    h = C.c_void_p(img)
+    assert L.vxReleaseImage(C.byref(h)) == ovx.VX_SUCCESS and h.value is None
+    assert L.vxReleaseImage(C.byref(h)) == ovx.VX_SUCCESS
+    for kind in ("Array", "Delay", "Node", "Graph", "Pyramid", "Scalar"):
+        z = C.c_void_p(None)
+        assert getattr(L, f"vxRelease{kind}")(C.byref(z)) == ovx.VX_SUCCESS
+    assert L.vxReleaseArray(C.byref(C.c_void_p(kp))) == ovx.VX_SUCCESS
+    # wrong handle type is refused
+    assert L.vxReleaseImage(C.byref(C.c_void_p(arr))) == ovx.VX_ERROR_INVALID_REFERENCE
+
+
+def test_error_objects(ctx):
+    for bad in (L.vxCreateImage(ctx, 0, 10, ovx.VX_DF_IMAGE_U8), L.vxCreateImage(ctx, 10, 10, 0x12345678),
+                L.vxCreateArray(ctx, 0x7777, 10), L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 0),
+                L.vxCreatePyramid(ctx, 0, 0.5, 64, 64, ovx.VX_DF_IMAGE_U8),
+                L.vxCreatePyramid(ctx, 4, 0.8408964, 64, 64, ovx.VX_DF_IMAGE_U8),
+                L.vxCreatePyramid(ctx, 4, 0.5, 64, 64, ovx.VX_DF_IMAGE_RGBX)):
+        assert bad is not None and L.vxGetStatus(bad) != ovx.VX_SUCCESS          # NVXIO_CHECK_REFERENCE would throw
+        assert ovx.query("vxQueryReference", bad, ovx.VX_REFERENCE_TYPE, C.c_int32) == ovx.VX_TYPE_ERROR
+    assert L.vxGetStatus(None) != ovx.VX_SUCCESS
+    img = L.vxCreateImage(ctx, 8, 8, ovx.VX_DF_IMAGE_U8)
+    g = L.vxCreateGraph(ctx)
+    n = L.vxColorConvertNode(g, None, img)                                        # required parameter missing
+    assert L.vxGetStatus(n) == ovx.VX_ERROR_INVALID_PARAMETERS
+    arr = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 4)
+    n = L.vxColorConvertNode(g, arr, img)                                         # wrong object type
+    assert L.vxGetStatus(n) == ovx.VX_ERROR_INVALID_REFERENCE
+
+
+def test_log_callback(ctx):
+    seen = []
+    cb = ovx.LOG_CALLBACK(lambda c, r, st, msg: seen.append((st, msg.decode())))
+    L.vxRegisterLogCallback(ctx, cb, 0)
+    L.vxCreateImage(ctx, 0, 0, ovx.VX_DF_IMAGE_U8)
+    assert seen and seen[0][0] == ovx.VX_ERROR_INVALID_DIMENSION and "vxCreateImage" in seen[0][1]
+
+
+def test_pyramid_levels_and_level_ownership(ctx):
+    pyr = L.vxCreatePyramid(ctx, 5, 0.5, 1920, 1080, ovx.VX_DF_IMAGE_U8)
+    assert ovx.query("vxQueryPyramid", pyr, ovx.VX_PYRAMID_LEVELS, C.c_size_t) == 5
+    dims = []
+    for i in range(5):
+        lv = L.vxGetPyramidLevel(pyr, i)
+        dims.append((ovx.query("vxQueryImage", lv, ovx.VX_IMAGE_WIDTH, C.c_uint32),
+                     ovx.query("vxQueryImage", lv, ovx.VX_IMAGE_HEIGHT, C.c_uint32)))
+        assert ovx.query("vxQueryReference", lv, ovx.VX_REFERENCE_COUNT, C.c_uint32) == 2   # pyramid's + ours (owned)
+        assert ovx.release("Image", lv) == ovx.VX_SUCCESS                                     # feature_tracker.cpp:448
+    assert dims == [(1920, 1080), (960, 540), (480, 270), (240, 135), (120, 68)]              # float ceil sizing
+    assert L.vxGetStatus(L.vxGetPyramidLevel(pyr, 5)) == ovx.VX_ERROR_INVALID_PARAMETERS
+    # a level that outlives its pyramid stays valid
+    lv0 = L.vxGetPyramidLevel(pyr, 0)
+    assert ovx.release("Pyramid", pyr) == ovx.VX_SUCCESS
+    assert ovx.query("vxQueryImage", lv0, ovx.VX_IMAGE_WIDTH, C.c_uint32) == 1920
+    assert ovx.release("Image", lv0) == ovx.VX_SUCCESS
+
+
+def test_delay_slots_keep_their_index(ctx):
+    ex = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 16)
+    d = L.vxCreateDelay(ctx, ex, 3)
+    assert ovx.release("Array", ex) == ovx.VX_SUCCESS                  # exemplar is cloned (feature_tracker.cpp:300-302)
+    assert ovx.query("vxQueryDelay", d, ovx.VX_DELAY_SLOTS, C.c_size_t) == 3
+    assert ovx.query("vxQueryDelay", d, ovx.VX_DELAY_TYPE, C.c_int32) == ovx.VX_TYPE_ARRAY
+    s = [L.vxGetReferenceFromDelay(d, -i) for i in range(3)]
+    assert len(set(s)) == 3
+    assert all(ovx.query("vxQueryArray", x, ovx.VX_ARRAY_CAPACITY, C.c_size_t) == 16 for x in s)
+    assert L.vxGetStatus(L.vxGetReferenceFromDelay(d, 1)) != ovx.VX_SUCCESS
+    assert L.vxGetStatus(L.vxGetReferenceFromDelay(d, -3)) != ovx.VX_SUCCESS
+    # borrowed: the count stays 1
+    assert ovx.query("vxQueryReference", s[0], ovx.VX_REFERENCE_COUNT, C.c_uint32) == 1
+    assert L.vxAgeDelay(d) == ovx.VX_SUCCESS
+    assert [L.vxGetReferenceFromDelay(d, -i) for i in range(3)] == s    # handles stay bound to their index
+    # pyramids and images can be delayed too (feature_tracker.cpp:287-291, main_feature_tracker.cpp:233-238)
+    pex = L.vxCreatePyramid(ctx, 3, 0.5, 64, 48, ovx.VX_DF_IMAGE_U8)
+    pd = L.vxCreateDelay(ctx, pex, 2)
+    ovx.release("Pyramid", pex)
+    assert L.vxGetStatus(pd) == ovx.VX_SUCCESS and L.vxAgeDelay(pd) == ovx.VX_SUCCESS
+    g = L.vxCreateGraph(ctx)
+    assert L.vxGetStatus(L.vxCreateDelay(ctx, g, 2)) == ovx.VX_ERROR_NOT_SUPPORTED
+    assert ovx.release("Delay", d) == ovx.VX_SUCCESS
+
+
+def _ft_graph(ctx, w=320, h=240, levels=4, cap=500, harris=True, order="ft"):
+    """the graph of demos/feature_tracker/feature_tracker.cpp:350-449, nodes created in a chosen order"""
+    frame = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+    pex = L.vxCreatePyramid(ctx, levels, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
+    pyr_delay = L.vxCreateDelay(ctx, pex, 2)
+    ovx.release("Pyramid", pex)
+    aex = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, cap)
+    pts_delay = L.vxCreateDelay(ctx, aex, 2)
+    ovx.release("Array", aex)
+    kp_curr = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, cap)
+    g = L.vxCreateGraph(ctx)
+    pyr0 = L.vxGetReferenceFromDelay(pyr_delay, 0)
+    gray = L.vxGetPyramidLevel(pyr0, 0)
+    eps, it, est = ovx.scalar(ctx, ovx.VX_TYPE_FLOAT32, 0.01), ovx.scalar(ctx, ovx.VX_TYPE_UINT32, 5), ovx.scalar(ctx, ovx.VX_TYPE_BOOL, 0)
+    mk = {
+        "cvt": lambda: L.vxColorConvertNode(g, frame, gray),
+        "pyr": lambda: L.vxGaussianPyramidNode(g, gray, pyr0),
+        "lk": lambda: L.vxOpticalFlowPyrLKNode(g, L.vxGetReferenceFromDelay(pyr_delay, -1), pyr0,
+                                               L.vxGetReferenceFromDelay(pts_delay, -1), L.vxGetReferenceFromDelay(pts_delay, -1),
+                                               kp_curr, ovx.VX_TERM_CRITERIA_BOTH, eps, it, est, 10),
+        "det": lambda: (L.nvxHarrisTrackNode(g, gray, L.vxGetReferenceFromDelay(pts_delay, 0), None, kp_curr, 0.04, 100.0, 18, None)
+                        if harris else
+                        L.nvxFastTrackNode(g, gray, L.vxGetReferenceFromDelay(pts_delay, 0), None, kp_curr, 9, 25, 18, None)),
+    }
+    names = {"ft": ["cvt", "pyr", "lk", "det"], "reversed": ["det", "lk", "pyr", "cvt"], "mixed": ["lk", "cvt", "det", "pyr"]}[order]
+    nodes = {n: mk[n]() for n in names}
+    for n in nodes.values():
+        assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+    return dict(g=g, nodes=nodes, frame=frame, gray=gray, pyr_delay=pyr_delay, pts_delay=pts_delay, kp_curr=kp_curr,
+                scalars=(eps, it, est))
+
+
+def _order(g):
+    buf = (C.c_int * 8)()
+    n = L.visualslam_amd_graph_order(g, buf, 8)
+    return list(buf[:n])
+
+
+@pytest.mark.parametrize("creation", ["ft", "reversed", "mixed"])
+@pytest.mark.parametrize("harris", [True, False])
+def test_verify_orders_nodes_by_data_dependency(ctx, creation, harris):
+    """the order ColorConvert -> GaussianPyramid -> PyrLK -> Harris/FastTrack is written
+    nowhere; vxVerifyGraph must derive it from the data (level 0 aliasing included)."""
+    ft = _ft_graph(ctx, harris=harris, order=creation)
+    opt = b"-O3"
+    assert L.vxSetGraphAttribute(ft["g"], ovx.NVX_GRAPH_VERIFY_OPTIONS, opt, len(opt)) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(ft["g"]) == ovx.VX_SUCCESS
+    assert L.vxIsGraphVerified(ft["g"]) == 1
+    det = ovx.K_HARRIS_TRACK if harris else ovx.K_FAST_TRACK
+    assert _order(ft["g"]) == [ovx.K_COLOR_CONVERT, ovx.K_GAUSSIAN_PYRAMID, ovx.K_PYRLK, det]
+    assert ovx.query("vxQueryGraph", ft["g"], ovx.VX_GRAPH_NUMNODES, C.c_uint32) == 4
+
+
+def test_scalars_and_nodes_can_be_released_after_verify(ctx):
+    ft = _ft_graph(ctx)
+    assert L.vxVerifyGraph(ft["g"]) == ovx.VX_SUCCESS
+    for s in ft["scalars"]:
+        assert ovx.release("Scalar", s) == ovx.VX_SUCCESS          # feature_tracker.cpp:445-447: node retains
+    assert ovx.release("Image", ft["gray"]) == ovx.VX_SUCCESS        # :448
+    for n in ft["nodes"].values():
+        assert ovx.release("Node", n) == ovx.VX_SUCCESS              # :264-267: the graph keeps its nodes
+    assert ovx.query("vxQueryGraph", ft["g"], ovx.VX_GRAPH_NUMNODES, C.c_uint32) == 4
+    assert L.vxIsGraphVerified(ft["g"]) == 1
+    assert ovx.release("Graph", ft["g"]) == ovx.VX_SUCCESS
+
+
+def test_set_parameter_by_index_rebinding(ctx):
+    ft = _ft_graph(ctx)
+    g, nodes = ft["g"], ft["nodes"]
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    frame2 = L.vxCreateImage(ctx, 320, 240, ovx.VX_DF_IMAGE_RGBX)
+    mask = L.vxCreateImage(ctx, 320, 240, ovx.VX_DF_IMAGE_U8)
+    # feature_tracker.cpp:216-217: new frame + (possibly NULL) mask every frame, no re-verification
+    assert L.vxSetParameterByIndex(nodes["cvt"], 0, frame2) == ovx.VX_SUCCESS
+    assert L.vxSetParameterByIndex(nodes["det"], 2, mask) == ovx.VX_SUCCESS
+    assert L.vxSetParameterByIndex(nodes["det"], 2, None) == ovx.VX_SUCCESS
+    assert L.vxIsGraphVerified(g) == 1
+    assert L.vxSetParameterByIndex(nodes["cvt"], 0, None) == ovx.VX_ERROR_INVALID_PARAMETERS      # required
+    assert L.vxSetParameterByIndex(nodes["cvt"], 0, mask) == ovx.VX_SUCCESS                        # other metadata ...
+    assert L.vxIsGraphVerified(g) == 0                                                             # ... needs re-verify
+    assert L.vxSetParameterByIndex(nodes["cvt"], 7, frame2) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxSetParameterByIndex(nodes["det"], 1, frame2) == ovx.VX_ERROR_INVALID_REFERENCE      # array expected
+    # the old frame was released by the node, the new one retained
+    assert ovx.query("vxQueryReference", ft["frame"], ovx.VX_REFERENCE_COUNT, C.c_uint32) == 1
+    assert ovx.query("vxQueryReference", mask, ovx.VX_REFERENCE_COUNT, C.c_uint32) == 2
+
+
+def test_verify_rejects_bad_graphs(ctx):
+    g = L.vxCreateGraph(ctx)
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_GRAPH                     # empty
+    a = L.vxCreateImage(ctx, 16, 16, ovx.VX_DF_IMAGE_U8)
+    b = L.vxCreateImage(ctx, 16, 16, ovx.VX_DF_IMAGE_U8)
+    L.nvxCopyImageNode(g, a, b)
+    L.nvxCopyImageNode(g, b, a)
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_GRAPH                     # cycle
+    g2 = L.vxCreateGraph(ctx)
+    c = L.vxCreateImage(ctx, 16, 16, ovx.VX_DF_IMAGE_U8)
+    L.nvxCopyImageNode(g2, a, c)
+    L.nvxCopyImageNode(g2, b, c)
+    assert L.vxVerifyGraph(g2) == ovx.VX_ERROR_INVALID_GRAPH                    # two writers
+    g3 = L.vxCreateGraph(ctx)
+    kp = L.vxCreateArray(ctx, ovx.VX_TYPE_KEYPOINT, 10)
+    L.nvxHarrisTrackNode(g3, a, kp, None, None, 0.04, 100.0, 18, None)
+    assert L.vxVerifyGraph(g3) == ovx.VX_ERROR_NOT_SUPPORTED                    # integer vx_keypoint_t not offered
+    g4 = L.vxCreateGraph(ctx)
+    p2 = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 10)
+    L.nvxHarrisTrackNode(g4, a, p2, None, None, 0.04, 100.0, 0, None)
+    assert L.vxVerifyGraph(g4) == ovx.VX_ERROR_INVALID_VALUE                    # cell_size 0
+
+
+def test_scalar_read_write(ctx):
+    s = ovx.scalar(ctx, ovx.VX_TYPE_FLOAT32, 0.25)
+    v = C.c_float()
+    assert L.vxReadScalarValue(s, C.byref(v)) == 0 and v.value == 0.25
+    v.value = 4.5
+    assert L.vxWriteScalarValue(s, C.byref(v)) == 0
+    w = C.c_float()
+    assert L.vxCopyScalar(s, C.byref(w), ovx.VX_READ_ONLY, ovx.VX_MEMORY_TYPE_HOST) == 0 and w.value == 4.5
+    assert ovx.query("vxQueryScalar", s, 0x80D00, C.c_int32) == ovx.VX_TYPE_FLOAT32
+
+
+def test_context_release_reclaims_everything(monkeypatch):
+    monkeypatch.setenv("VISUALSLAM_AMD_ALLOW_NO_GPU", "1")
+    c = L.vxCreateContext()
+    ft = _ft_graph(c)
+    assert L.vxVerifyGraph(ft["g"]) == ovx.VX_SUCCESS
+    h = C.c_void_p(c)
+    assert L.vxReleaseContext(C.byref(h)) == ovx.VX_SUCCESS          # nothing released by hand: no crash, no leak report
+    assert L.vxGetStatus(ft["g"]) == ovx.VX_ERROR_INVALID_REFERENCE  # handles are dead afterwards

@@ -1,0 +1,204 @@
+"""ctypes binding of the OpenVX-subset C API (include/VX/vx.h, VX/vxu.h, NVX/nvx.h) exported by
+libvisualslam_amd.so -- plumbing for tests and bench.py; every call goes straight through the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import nvxcu
+
+VX_SUCCESS = 0
+VX_FAILURE = -1
+VX_ERROR_NOT_SUPPORTED = -3
+VX_ERROR_INVALID_PARAMETERS = -10
+VX_ERROR_INVALID_REFERENCE = -12
+VX_ERROR_INVALID_FORMAT = -14
+VX_ERROR_INVALID_DIMENSION = -15
+VX_ERROR_INVALID_VALUE = -16
+VX_ERROR_INVALID_TYPE = -17
+VX_ERROR_INVALID_GRAPH = -18
+NVX_ERROR_NO_GPU = -1000
+
+VX_TYPE_UINT32, VX_TYPE_FLOAT32, VX_TYPE_SIZE, VX_TYPE_BOOL, VX_TYPE_ENUM = 0x007, 0x00A, 0x00D, 0x010, 0x00C
+VX_TYPE_KEYPOINT = 0x021
+VX_TYPE_IMAGE, VX_TYPE_ARRAY, VX_TYPE_PYRAMID, VX_TYPE_ERROR = 0x80F, 0x80E, 0x809, 0x811
+NVX_TYPE_POINT2F, NVX_TYPE_KEYPOINTF = 0x400, 0x403
+VX_DF_IMAGE_U8, VX_DF_IMAGE_RGBX = nvxcu.NVXCU_DF_IMAGE_U8, nvxcu.NVXCU_DF_IMAGE_RGBX
+VX_IMAGE_WIDTH, VX_IMAGE_HEIGHT, VX_IMAGE_FORMAT, VX_IMAGE_PLANES = 0x80F00, 0x80F01, 0x80F02, 0x80F03
+VX_ARRAY_ITEMTYPE, VX_ARRAY_NUMITEMS, VX_ARRAY_CAPACITY, VX_ARRAY_ITEMSIZE = 0x80E00, 0x80E01, 0x80E02, 0x80E03
+VX_PYRAMID_LEVELS = 0x80900
+VX_DELAY_TYPE, VX_DELAY_SLOTS = 0x80600, 0x80601
+VX_GRAPH_NUMNODES, VX_GRAPH_PERFORMANCE, VX_GRAPH_STATE = 0x80200, 0x80202, 0x80204
+VX_NODE_PERFORMANCE = 0x80301
+VX_REFERENCE_COUNT, VX_REFERENCE_TYPE = 0x80000, 0x80001
+VX_DIRECTIVE_ENABLE_PERFORMANCE = 0x03003
+VX_READ_ONLY, VX_WRITE_ONLY, VX_READ_AND_WRITE = 0x11001, 0x11002, 0x11003
+VX_MEMORY_TYPE_HOST, NVX_MEMORY_TYPE_HIP = 0x0E001, 0x0E100
+VX_TERM_CRITERIA_ITERATIONS, VX_TERM_CRITERIA_EPSILON, VX_TERM_CRITERIA_BOTH = 0x17000, 0x17001, 0x17002
+NVX_GRAPH_VERIFY_OPTIONS = 0x80280
+VX_SCALE_PYRAMID_HALF = 0.5
+K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE = range(6)
+
+
+class vx_perf_t(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("tmp", "beg", "end", "sum", "avg", "min", "num", "max")]
+
+
+class vx_rectangle_t(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("start_x", "start_y", "end_x", "end_y")]
+
+
+class vx_imagepatch_addressing_t(C.Structure):
+    _fields_ = [("dim_x", C.c_uint32), ("dim_y", C.c_uint32), ("stride_x", C.c_int32), ("stride_y", C.c_int32),
+                ("scale_x", C.c_uint32), ("scale_y", C.c_uint32), ("step_x", C.c_uint32), ("step_y", C.c_uint32)]
+
+
+LOG_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32, C.c_char_p)
+
+_SIGS = {
+    "vxCreateContext": (C.c_void_p, []),
+    "vxReleaseContext": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxGetContext": (C.c_void_p, [C.c_void_p]),
+    "vxGetStatus": (C.c_int32, [C.c_void_p]),
+    "vxDirective": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "vxRegisterLogCallback": (None, [C.c_void_p, LOG_CALLBACK, C.c_int]),
+    "vxQueryReference": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxRetainReference": (C.c_int32, [C.c_void_p]),
+    "vxReleaseReference": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxCreateImage": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "vxReleaseImage": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxQueryImage": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxMapImagePatch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t),
+                                    C.POINTER(vx_imagepatch_addressing_t), C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_uint32]),
+    "vxUnmapImagePatch": (C.c_int32, [C.c_void_p, C.c_size_t]),
+    "vxCopyImagePatch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(vx_imagepatch_addressing_t), C.c_void_p, C.c_int32, C.c_int32]),
+    "vxCreatePyramid": (C.c_void_p, [C.c_void_p, C.c_size_t, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "vxReleasePyramid": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxQueryPyramid": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxGetPyramidLevel": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "vxCreateArray": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_size_t]),
+    "vxReleaseArray": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxQueryArray": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxAddArrayItems": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "vxTruncateArray": (C.c_int32, [C.c_void_p, C.c_size_t]),
+    "vxMapArrayRange": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                    C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_uint32]),
+    "vxUnmapArrayRange": (C.c_int32, [C.c_void_p, C.c_size_t]),
+    "vxCopyArrayRange": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int32, C.c_int32]),
+    "vxAccessArrayRange": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.c_int32]),
+    "vxCommitArrayRange": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "vxCreateScalar": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "vxReleaseScalar": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxQueryScalar": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxReadScalarValue": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "vxWriteScalarValue": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "vxCopyScalar": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "vxCreateDelay": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "vxReleaseDelay": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxQueryDelay": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxGetReferenceFromDelay": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "vxAgeDelay": (C.c_int32, [C.c_void_p]),
+    "vxCreateGraph": (C.c_void_p, [C.c_void_p]),
+    "vxReleaseGraph": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxVerifyGraph": (C.c_int32, [C.c_void_p]),
+    "vxProcessGraph": (C.c_int32, [C.c_void_p]),
+    "vxScheduleGraph": (C.c_int32, [C.c_void_p]),
+    "vxWaitGraph": (C.c_int32, [C.c_void_p]),
+    "vxQueryGraph": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxSetGraphAttribute": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxIsGraphVerified": (C.c_int, [C.c_void_p]),
+    "vxReleaseNode": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxQueryNode": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxSetParameterByIndex": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "vxColorConvertNode": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vxGaussianPyramidNode": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vxOpticalFlowPyrLKNode": (C.c_void_p, [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "nvxHarrisTrackNode": (C.c_void_p, [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
+    "nvxFastTrackNode": (C.c_void_p, [C.c_void_p] * 5 + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "nvxCopyImageNode": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vxuColorConvert": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vxuGaussianPyramid": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vxuOpticalFlowPyrLK": (C.c_int32, [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "nvxuHarrisTrack": (C.c_int32, [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
+    "nvxuFastTrack": (C.c_int32, [C.c_void_p] * 5 + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "nvxuCopyImage": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "visualslam_amd_graph_order": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = nvxcu.lib()
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status != VX_SUCCESS:
+        raise RuntimeError(f"{what} failed with vx_status {status}")
+
+
+def release(kind, handle):
+    """vxRelease<kind>(&handle); returns the status."""
+    h = C.c_void_p(handle)
+    return getattr(lib(), f"vxRelease{kind}")(C.byref(h))
+
+
+def query(fn_name, obj, attr, ctype):
+    v = ctype()
+    check(getattr(lib(), fn_name)(obj, attr, C.byref(v), C.sizeof(v)), fn_name)
+    return v.value if hasattr(v, "value") else v
+
+
+def scalar(ctx, vx_type, value):
+    ct = {VX_TYPE_FLOAT32: C.c_float, VX_TYPE_UINT32: C.c_uint32, VX_TYPE_BOOL: C.c_int, VX_TYPE_SIZE: C.c_size_t,
+          VX_TYPE_ENUM: C.c_int32}[vx_type]
+    v = ct(value)
+    return lib().vxCreateScalar(ctx, vx_type, C.byref(v))
+
+
+def write_image(img, arr):
+    """host numpy array (h, w) u8 or (h, w, 4) u8 -> vx_image via vxCopyImagePatch"""
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    h, w = arr.shape[:2]
+    bpp = 4 if arr.ndim == 3 else 1
+    addr = vx_imagepatch_addressing_t(w, h, bpp, w * bpp, 1024, 1024, 1, 1)
+    check(lib().vxCopyImagePatch(img, None, 0, C.byref(addr), arr.ctypes.data, VX_WRITE_ONLY, VX_MEMORY_TYPE_HOST), "vxCopyImagePatch(write)")
+
+
+def read_image(img):
+    w = query("vxQueryImage", img, VX_IMAGE_WIDTH, C.c_uint32)
+    h = query("vxQueryImage", img, VX_IMAGE_HEIGHT, C.c_uint32)
+    fmt = query("vxQueryImage", img, VX_IMAGE_FORMAT, C.c_uint32)
+    bpp = 4 if fmt == VX_DF_IMAGE_RGBX else 1
+    out = np.empty((h, w, 4) if bpp == 4 else (h, w), np.uint8)
+    addr = vx_imagepatch_addressing_t(w, h, bpp, w * bpp, 1024, 1024, 1, 1)
+    check(lib().vxCopyImagePatch(img, None, 0, C.byref(addr), out.ctypes.data, VX_READ_ONLY, VX_MEMORY_TYPE_HOST), "vxCopyImagePatch(read)")
+    return out
+
+
+def num_items(arr):
+    return query("vxQueryArray", arr, VX_ARRAY_NUMITEMS, C.c_size_t)
+
+
+def read_array(arr, dtype=None):
+    n = num_items(arr)
+    isz = query("vxQueryArray", arr, VX_ARRAY_ITEMSIZE, C.c_size_t)
+    raw = np.empty(n * isz, np.uint8)
+    if n:
+        check(lib().vxCopyArrayRange(arr, 0, n, isz, raw.ctypes.data, VX_READ_ONLY, VX_MEMORY_TYPE_HOST), "vxCopyArrayRange")
+    if dtype is not None:
+        return raw.view(dtype).copy()
+    return raw.view(np.float32).reshape(n, 2).copy() if isz == 8 else raw
+
+
+def add_items(arr, items):
+    items = np.ascontiguousarray(items)
+    n = len(items)
+    isz = items.dtype.itemsize if items.ndim == 1 else items.dtype.itemsize * items.shape[1]
+    check(lib().vxAddArrayItems(arr, n, items.ctypes.data, isz), "vxAddArrayItems")
