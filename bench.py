@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--streams", type=int, default=4, help="camera streams per GPU")
     ap.add_argument("--ring", type=int, default=8, help="pre-generated frames resident in HBM")
+    ap.add_argument("--api", choices=["ovx", "thin"], default="ovx",
+                    help="ovx: OpenVX graph API (default, the north-star path); thin: nvxcu primitives")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -91,8 +93,7 @@ def main():
     import torch
 
     from visualslam_amd import nvxcu, synth
-    from visualslam_amd.devmem import DeviceImage
-    from visualslam_amd.thin_tracker import Params, ThinFeatureTracker
+    from visualslam_amd.thin_tracker import Params
 
     if world > 1:
         import torch.distributed as dist
@@ -112,36 +113,82 @@ def main():
 
     base = synth.base_frame(WIDTH, HEIGHT, 1234)
     host_frames = [synth.to_rgbx(synth.gray_frame(base, t, 1234)) for t in range(args.ring)]
-    ring = [DeviceImage(WIDTH, HEIGHT, nvxcu.NVXCU_DF_IMAGE_RGBX, device).upload(f) for f in host_frames]
+    phases = [(s * 3) % args.ring for s in my_streams]     # streams look at different frames
 
-    trackers = [ThinFeatureTracker(params, WIDTH, HEIGHT, device, torch.cuda.Stream(device)) for _ in my_streams]
-    for i, trk in enumerate(trackers):
-        trk.phase = (my_streams[i] * 3) % args.ring      # streams look at different frames
-        trk.init(ring[trk.phase].desc)
+    if args.api == "ovx":
+        # the north-star path: one OpenVX graph per camera stream (ColorConvert -> GaussianPyramid ->
+        # OpticalFlowPyrLK -> HarrisTrack), per frame vxSetParameterByIndex x2 + vxAgeDelay x2 +
+        # vxScheduleGraph, as demos/feature_tracker/feature_tracker.cpp:216-224 drives it
+        import ctypes as C
+        from visualslam_amd import ovx
+        from visualslam_amd.vx_tracker import VxFeatureTracker
+        L = ovx.lib()
+        ctx = L.vxCreateContext()
+        ovx.check(L.vxGetStatus(ctx), "vxCreateContext")
+        ovx.check(L.vxDirective(ctx, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))   # per-node HIP events
+        ring = []
+        for f in host_frames:
+            img = L.vxCreateImage(ctx, WIDTH, HEIGHT, ovx.VX_DF_IMAGE_RGBX)
+            ovx.write_image(img, f)
+            ring.append(img)
+        trackers = [VxFeatureTracker(ctx, params, WIDTH, HEIGHT, ring[ph], None) for ph in phases]
+
+        def step(k):
+            for trk, ph in zip(trackers, phases):
+                trk.track(ring[(ph + 1 + k) % args.ring], None, schedule_only=True)
+            for trk in trackers:
+                trk.wait()
+
+        def lk_launch_ms():
+            perf = ovx.query("vxQueryNode", trackers[0].lk, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
+            return perf.avg * 1e-6, int(perf.num)
+
+        def counts():
+            cur = [trk.curr() for trk in trackers]
+            return [int((c[:, 0] >= 0).sum()) for c in cur], [len(c) for c in cur]
+        api_desc = "OpenVX graph C API (VX/vx.h): vxScheduleGraph/vxWaitGraph per frame, one graph + HIP stream per camera stream"
+    else:
+        from visualslam_amd.devmem import DeviceImage
+        from visualslam_amd.thin_tracker import ThinFeatureTracker
+        ring = [DeviceImage(WIDTH, HEIGHT, nvxcu.NVXCU_DF_IMAGE_RGBX, device).upload(f) for f in host_frames]
+        trackers = [ThinFeatureTracker(params, WIDTH, HEIGHT, device, torch.cuda.Stream(device)) for _ in my_streams]
+        for trk, ph in zip(trackers, phases):
+            trk.init(ring[ph].desc)
+
+        def step(k):
+            for trk, ph in zip(trackers, phases):
+                trk.track(ring[(ph + 1 + k) % args.ring].desc)
+
+        def lk_launch_ms():
+            pairs = trackers[0].lk_events or []
+            return (float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else float("nan")), len(pairs)
+
+        def counts():
+            cur = [trk.curr_features() for trk in trackers]
+            return [int((c[:, 0] >= 0).sum()) for c in cur], [len(c) for c in cur]
+        api_desc = "thin C ABI (NVX/nvxcu.h), eager launches, one HIP stream per camera stream"
     torch.cuda.synchronize()
-
-    def step(k):
-        for trk in trackers:
-            trk.track(ring[(trk.phase + 1 + k) % args.ring].desc)
 
     for k in range(args.warmup):
         step(k)
     torch.cuda.synchronize()
     barrier(world)
-    trackers[0].lk_events = []
+    if args.api == "thin":
+        trackers[0].lk_events = []
+    lk_before = lk_launch_ms() if args.api == "ovx" else (0.0, 0)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier(world)
-    lk_pairs, trackers[0].lk_events = trackers[0].lk_events, None
     elapsed = reduce_max(elapsed, world)
 
-    # tracks alive at the end (diagnostic) and the PyrLK launch duration from its HIP events
-    n_tracks = [int((trk.curr_features()[:, 0] >= 0).sum()) for trk in trackers]
-    n_points = [trk.prev_pts.num_items() for trk in trackers]
-    lk_ms = float(np.mean([a.elapsed_time(b) for a, b in lk_pairs])) if lk_pairs else float("nan")
+    # PyrLK launch duration from HIP events recorded on its stream during the timed region
+    lk_ms, lk_n = lk_launch_ms()
+    if args.api == "ovx" and lk_n > lk_before[1]:
+        lk_ms = (lk_ms * lk_n - lk_before[0] * lk_before[1]) / (lk_n - lk_before[1])
+    n_tracks, n_points = counts()
 
     if rank == 0:
         frames = args.steps * args.streams * world
@@ -158,7 +205,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD, "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
-                       "frame_ring": args.ring, "api": "thin C ABI (NVX/nvxcu.h), eager launches, one HIP stream per camera stream"},
+                       "frame_ring": args.ring, "api": api_desc},
             "tracks_per_sec": fps * float(np.mean(n_tracks)),
             "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),
             "frame_algorithmic_GBps": BYTES_FRAME * fps / 1e9,

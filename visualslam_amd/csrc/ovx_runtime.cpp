@@ -199,7 +199,10 @@ vx_status ensure_image(_vx_image *im)
     im->pitch = (im->width * im->bpp + kPitchAlign - 1) / kPitchAlign * kPitchAlign;
     void *p = nullptr;
     if (hipMalloc(&p, (size_t)im->pitch * im->height + kRowSlack) != hipSuccess) return VX_ERROR_NO_MEMORY;
-    if (hipMemset(p, 0, (size_t)im->pitch * im->height + kRowSlack) != hipSuccess) return VX_FAILURE;
+    // hipMemset is asynchronous on the null stream and our streams are non-blocking: finish it now,
+    // or it could land after the first kernel that writes this image
+    if (hipMemset(p, 0, (size_t)im->pitch * im->height + kRowSlack) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess) return VX_FAILURE;
     im->dev = static_cast<uint8_t *>(p);
     return VX_SUCCESS;
 }
@@ -220,7 +223,7 @@ vx_status ensure_array(_vx_array *a)
     const size_t payload = (a->capacity * a->item_size + 15) & ~(size_t)15;
     void *p = nullptr;
     if (hipMalloc(&p, payload + 16) != hipSuccess) return VX_ERROR_NO_MEMORY;
-    if (hipMemset(p, 0, payload + 16) != hipSuccess) return VX_FAILURE;
+    if (hipMemset(p, 0, payload + 16) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return VX_FAILURE;
     a->dev = static_cast<uint8_t *>(p);
     a->dev_count = reinterpret_cast<uint32_t *>(a->dev + payload);
     if (a->num_items) {
