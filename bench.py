@@ -76,10 +76,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--streams", type=int, default=4, help="camera streams per GPU")
+    ap.add_argument("--streams", type=int, default=8, help="camera streams per GPU")
     ap.add_argument("--ring", type=int, default=8, help="pre-generated frames resident in HBM")
     ap.add_argument("--api", choices=["ovx", "thin"], default="ovx",
                     help="ovx: OpenVX graph API (default, the north-star path); thin: nvxcu primitives")
+    ap.add_argument("--host-threads", type=int, default=1,
+                    help="ovx: 1 = one host thread per camera stream calling vxProcessGraph (default); 0 = one thread scheduling all graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,6 +141,13 @@ def main():
             for trk in trackers:
                 trk.wait()
 
+        def run_stream(i, k0, n):
+            # one host thread per camera stream, synchronous vxProcessGraph per frame exactly as the
+            # reference application calls it; streams overlap on the GPU because each graph owns a HIP stream
+            trk, ph = trackers[i], phases[i]
+            for k in range(k0, k0 + n):
+                trk.track(ring[(ph + 1 + k) % args.ring], None)
+
         def lk_launch_ms():
             perf = ovx.query("vxQueryNode", trackers[0].lk, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
             return perf.avg * 1e-6, int(perf.num)
@@ -146,7 +155,8 @@ def main():
         def counts():
             cur = [trk.curr() for trk in trackers]
             return [int((c[:, 0] >= 0).sum()) for c in cur], [len(c) for c in cur]
-        api_desc = "OpenVX graph C API (VX/vx.h): vxScheduleGraph/vxWaitGraph per frame, one graph + HIP stream per camera stream"
+        api_desc = ("OpenVX graph C API (VX/vx.h): one graph + HIP stream per camera stream, " +
+                    ("one host thread per stream calling vxProcessGraph" if args.host_threads else "one host thread, vxScheduleGraph/vxWaitGraph"))
     else:
         from visualslam_amd.devmem import DeviceImage
         from visualslam_amd.thin_tracker import ThinFeatureTracker
@@ -169,16 +179,27 @@ def main():
         api_desc = "thin C ABI (NVX/nvxcu.h), eager launches, one HIP stream per camera stream"
     torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
+    def run(k0, n):
+        """n steps (= n frames on every camera stream of this GPU) starting at frame index k0"""
+        if args.api == "ovx" and args.host_threads:
+            import threading
+            ths = [threading.Thread(target=run_stream, args=(i, k0, n)) for i in range(len(trackers))]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        else:
+            for k in range(k0, k0 + n):
+                step(k)
+
+    run(0, args.warmup)
     torch.cuda.synchronize()
     barrier(world)
     if args.api == "thin":
         trackers[0].lk_events = []
     lk_before = lk_launch_ms() if args.api == "ovx" else (0.0, 0)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
+    run(args.warmup, args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier(world)
