@@ -117,7 +117,10 @@ __global__ __launch_bounds__(256) void k_corner_cells(CornerArgs a)
     uint8_t *px = reinterpret_cast<uint8_t *>(DET == kHarris ? (void *)(grad + GW * GH) : (void *)grad);
 
     const int tid = threadIdx.x;
-    const int rx0 = blockIdx.x * a.nbx * a.cs, ry0 = blockIdx.y * a.nby * a.cs;
+    // each XCD owns a contiguous band of cell blocks (halo rows/columns are shared inside one L2)
+    const uint32_t item = xcd_contiguous_item(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int bx = (int)(item % gridDim.x), by = (int)(item / gridDim.x);
+    const int rx0 = bx * a.nbx * a.cs, ry0 = by * a.nby * a.cs;
     const int rw = min(a.nbx * a.cs, a.w - rx0), rh = min(a.nby * a.cs, a.h - ry0);
 
     for (int i = tid; i < ncl; i += 256) keys[i] = 0;
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void k_corner_cells(CornerArgs a)
     }
     __syncthreads();
     for (int i = tid; i < ncl; i += 256) {
-        const int cx = blockIdx.x * a.nbx + i % a.nbx, cy = blockIdx.y * a.nby + i / a.nbx;
+        const int cx = bx * a.nbx + i % a.nbx, cy = by * a.nby + i / a.nbx;
         if (cx < a.ncx && cy < a.ncy) a.cell_best[(size_t)cy * a.ncx + cx] = keys[i];
     }
 }

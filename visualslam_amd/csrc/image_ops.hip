@@ -121,8 +121,10 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_fused(PyrFusedArgs a)
 
     const int tid = threadIdx.x;
     int ox[5], oy[5];
-    ox[NS] = blockIdx.x * T;
-    oy[NS] = blockIdx.y * T;
+    // each XCD builds a contiguous band of tiles: the source halos neighbours share stay in one L2
+    const uint32_t item = xcd_contiguous_item(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    ox[NS] = (int)(item % gridDim.x) * T;
+    oy[NS] = (int)(item / gridDim.x) * T;
 #pragma unroll
     for (int g = NS; g > 0; --g) { ox[g - 1] = 2 * ox[g] - 2; oy[g - 1] = 2 * oy[g] - 2; }
 

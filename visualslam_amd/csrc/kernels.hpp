@@ -15,6 +15,20 @@ constexpr int kMaxPyrLevels = 10;
 constexpr int kLkMinWin = 3;
 constexpr int kLkMaxWin = 32;
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  This maps workgroup id `bid` of a
+// grid of `n` to a work item so that every XCD owns one CONTIGUOUS range of items (a bijection on [0,n)):
+// neighbouring items -- spatially neighbouring tiles / features -- then share an L2 instead of being
+// fetched once per XCD.
+constexpr uint32_t kNumXcd = 8;
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t xcd_contiguous_item(uint32_t bid, uint32_t n)
+{
+    const uint32_t q = n / kNumXcd, r = n % kNumXcd;
+    const uint32_t x = bid % kNumXcd, k = bid / kNumXcd;
+    return x * q + (x < r ? x : r) + k;
+}
+#endif
+
 enum ItemKind : int { kPoint2f = 0, kKeypointf = 1 };
 enum Detector : int { kHarris = 0, kFast = 1 };
 

@@ -153,10 +153,12 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
-    const uint32_t pi = blockIdx.x;
     const uint32_t n = min(*a.prev_count, a.capacity);
-    if (pi == 0 && lane == 0) *a.out_count = n;
-    if (pi >= n) return;
+    if (blockIdx.x == 0 && lane == 0) *a.out_count = n;
+    if (blockIdx.x >= n) return;
+    // features arrive in detector-cell raster order: consecutive features are image neighbours, so give
+    // each XCD a contiguous run of them (their tiles overlap in that XCD's L2)
+    const uint32_t pi = xcd_contiguous_item(blockIdx.x, n);
 
     float px, py, ex, ey;
     bool alive = true;
