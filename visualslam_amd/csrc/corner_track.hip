@@ -7,10 +7,12 @@
 // (cell selection/merge, Harris response and FAST strength functions).
 //
 // Two launches, no atomics on global memory, no host round trip:
-//   k_corner_cells<DET>  one workgroup OWNS a rectangle of whole detector cells; it walks that
-//                        rectangle in LDS-staged tiles (image read once + halo), computes the
-//                        score, the NMS and each cell's best (score, lowest raster index) as a
-//                        64-bit key, and stores one key per cell (0 = no corner).
+//   k_harris_cells /     one workgroup OWNS a rectangle of whole detector cells (image read once +
+//   k_fast_cells         halo), computes the score, the NMS and each cell's best (score, lowest
+//                        raster index) as a 64-bit key, and stores one key per cell (0 = no corner).
+//                        Harris: one wave per rectangle, lane = image column, rows streamed through
+//                        register sliding windows, horizontal neighbours by DPP wave shifts.
+//                        FAST: 256-thread workgroup over LDS-staged tiles.
 //   k_merge_compact      one workgroup marks cells that hold a surviving tracked point, then
 //                        compacts survivors (input order) and new corners (cell raster order)
 //                        with ballot/popcount prefix sums.
@@ -21,10 +23,9 @@
 namespace vsa {
 namespace {
 
-constexpr int TW = 64, TH = 40;         // tile interior (pixels)
-constexpr int HALO = 4;                 // Harris needs 3, FAST (radius 3 + NMS) needs 4
+constexpr int TW = 64, TH = 40;         // FAST tile interior (pixels)
+constexpr int HALO = 4;                 // FAST: radius 3 + NMS
 constexpr int PXW = TW + 2 * HALO, PXH = TH + 2 * HALO;
-constexpr int GW = TW + 4, GH = TH + 4; // gradient grid  (interior + 2)
 constexpr int SW = TW + 2, SH = TH + 2; // score grid     (interior + 1)
 constexpr uint64_t OCCUPIED = ~0ull;
 
@@ -105,16 +106,192 @@ __device__ __forceinline__ float fast_score(const uint8_t *c /* centre in LDS */
     return (float)(best - 1);
 }
 
-template <int DET>
-__global__ __launch_bounds__(256) void k_corner_cells(CornerArgs a)
+// ---- Harris: one wave per rectangle of cells, lane = column ----------------------------------
+constexpr int HS_USE = 55;    // owned columns per strip: 64 lanes - 3 right halo - (3..6) left halo (dword-aligned origin)
+constexpr int HS_ROWS = 48;   // owned rows per chunk (LDS tile height - 6)
+constexpr int HS_BAND = 24;   // preferred owned rows per wave: shorter bands = more waves per SIMD
+constexpr int HS_R = HS_ROWS + 6 + 2;   // LDS tile rows: owned + halo + the partial last triple
+constexpr int HS_NLD = (HS_R * 16 + 63) / 64;
+
+// Wave shifts are only ever issued as v_mov_b32_dpp: folded into an arithmetic instruction (what the
+// compiler's DPP combiner does with `right - left`) a wave_shr source read as zero on gfx950, so the
+// moved value is pinned in a register before it is used.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    int r = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+// value of the lane holding column x-1 / x+1 (0 beyond the wave; those lanes are halo)
+__device__ __forceinline__ int left_i(int v) { return dpp_i<0x138>(v); }    // wave_shr:1
+__device__ __forceinline__ int right_i(int v) { return dpp_i<0x130>(v); }   // wave_shl:1
+__device__ __forceinline__ float left_f(float v) { return __int_as_float(left_i(__float_as_int(v))); }
+__device__ __forceinline__ float right_f(float v) { return __int_as_float(right_i(__float_as_int(v))); }
+
+
+struct HarrisRows {
+    int hd[3], hs[3];             // per pixel row: right-left and left+2*centre+right   (ring, index = row % 3)
+    int hxx[3], hxy[3], hyy[3];   // per gradient row: horizontal 3-sums of the gradient products (ring)
+    float s[3];                   // score rows (ring)
+};
+
+// Per-tile constants of the streamed pass
+struct HarrisTile {
+    const uint8_t *col;        // LDS: this lane's column of the pixel tile (row stride 64)
+    int gx;                    // image column of this lane
+    int gy_tile0;              // image row of tile row 0
+    int th;                    // owned rows
+    bool col_valid, col_owned;
+    int cell_x, cell_row0;     // cell column of this lane, owned-row offset inside the rectangle (ty)
+    uint64_t *keys;
+};
+
+// One streamed tile row.  PH = r % 3 (compile time, so the rings live in registers without moves);
+// STAGES = how much of the pipeline is live (warm-up rows run fewer stages).  Pixel row r completes
+// gradient row r-1, tensor/score row r-2 and the NMS of row r-3.  All integer stages are exact, so the
+// separable evaluation order is free; the response is harris_r() as in the oracle.
+template <int PH, int STAGES>
+__device__ __forceinline__ void harris_row(HarrisRows &st, const CornerArgs &a, const HarrisTile &t, int r)
+{
+    constexpr int P0 = (PH + 1) % 3, P1 = (PH + 2) % 3, P2 = PH;   // ring slots of rows r-2, r-1, r
+    {
+        const int p = t.col[r * 64];
+        const int l = left_i(p), rt = right_i(p);
+        st.hd[P2] = rt - l;
+        st.hs[P2] = l + 2 * p + rt;
+    }
+    if (STAGES >= 2) {   // Sobel at gradient row r-1 -> ring slot P1
+        const int ix = st.hd[P0] + 2 * st.hd[P1] + st.hd[P2];
+        const int iy = st.hs[P2] - st.hs[P0];
+        const int xx = ix * ix, xy = ix * iy, yy = iy * iy;
+        st.hxx[P1] = left_i(xx) + xx + right_i(xx);
+        st.hxy[P1] = left_i(xy) + xy + right_i(xy);
+        st.hyy[P1] = left_i(yy) + yy + right_i(yy);
+    }
+    if (STAGES >= 3) {   // score row r-2 -> ring slot P0 (gradient rows r-3, r-2, r-1 = all three ring slots)
+        const int gy = t.gy_tile0 + r - 2;
+        const float v = harris_r(st.hxx[0] + st.hxx[1] + st.hxx[2], st.hxy[0] + st.hxy[1] + st.hxy[2],
+                                 st.hyy[0] + st.hyy[1] + st.hyy[2], a.k);
+        st.s[P0] = (t.col_valid && gy >= 2 && gy < a.h - 2) ? v : -INFINITY;
+    }
+    if (STAGES >= 4) {   // NMS row r-3 -> ring slot P2 ; above = r-4 -> P1 ; below = r-2 -> P0
+        const float c = st.s[P2];
+        bool cand = t.col_owned && (r - 6 < t.th) && (c >= a.thr) && (c != -INFINITY);
+        if (__ballot(cand) != 0ull) {   // wave-uniform: candidates are sparse
+            // every lane takes part in the shifts: neighbours are read before any divergence
+            const float up = st.s[P1], dn = st.s[P0];
+            const float ul = left_f(up), ur = right_f(up), cl = left_f(c), cr = right_f(c), dl = left_f(dn),
+                        dr = right_f(dn);
+            cand = cand && !(ul >= c) && !(up >= c) && !(ur >= c) && !(cl >= c) && !(cr > c) && !(dl > c) &&
+                   !(dn > c) && !(dr > c);
+            const int gy = t.gy_tile0 + r - 3;
+            if (cand && a.mask) cand = a.mask[(size_t)gy * a.mask_pitch + t.gx] != 0;
+            if (cand) {
+                const int cell = ((t.cell_row0 + r - 6) / a.cs) * a.nbx + t.cell_x;
+                const uint32_t idx = (uint32_t)gy * (uint32_t)a.w + (uint32_t)t.gx;
+                const uint64_t key = ((uint64_t)orderable(c) << 32) | (uint64_t)(~idx);
+                atomicMax(reinterpret_cast<unsigned long long *>(&t.keys[cell]), (unsigned long long)key);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_harris_cells(CornerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // carve: keys | score | grad (Harris only) | pixels
+    // carve: pixel tile (HS_R rows x 64 columns) | keys
+    uint8_t *tile = smem;
+    uint64_t *keys = reinterpret_cast<uint64_t *>(smem + HS_R * 64);
+    const int ncl = a.nbx * a.nby;
+    const int lane = threadIdx.x;
+
+    const uint32_t gxn = (uint32_t)(a.ncx + a.nbx - 1) / (uint32_t)a.nbx;
+    // each XCD owns a contiguous band of cell blocks (halo rows/columns are shared inside one L2)
+    const uint32_t item = xcd_contiguous_item(blockIdx.x, gridDim.x);
+    const int bx = (int)(item % gxn), by = (int)(item / gxn);
+    const int rx0 = bx * a.nbx * a.cs, ry0 = by * a.nby * a.cs;
+    const int rw = min(a.nbx * a.cs, a.w - rx0), rh = min(a.nby * a.cs, a.h - ry0);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.img) | a.pitch) & 3u) == 0;
+
+    for (int i = lane; i < ncl; i += 64) keys[i] = 0;
+
+    for (int ty = 0; ty < rh; ty += HS_ROWS) {
+        for (int tx = 0; tx < rw; tx += HS_USE) {
+            const int tw = min(HS_USE, rw - tx), th = min(HS_ROWS, rh - ty);
+            const int gx0 = rx0 + tx, gy0 = ry0 + ty;
+            const int xa = (gx0 - 3) & ~3;          // column of lane 0 (multiple of 4, may be negative)
+            const int R = th + 6;                   // tile rows: image rows gy0-3 .. gy0+th+2
+            __syncthreads();                        // previous tile fully consumed (orders the key init too)
+
+            // stage the tile: rows replicate-clamped; columns outside the image hold arbitrary in-bounds
+            // bytes (every score whose support touches them is invalid by definition)
+            if (aligned) {
+                const int xmax = (int)a.pitch - 4;
+                uint32_t v[HS_NLD];
+#pragma unroll
+                for (int i = 0; i < HS_NLD; ++i) {
+                    const int idx = lane + 64 * i, r = idx >> 4, d = idx & 15;   // load i covers tile rows 4i .. 4i+3
+                    const int gy = min(max(gy0 - 3 + r, 0), a.h - 1);
+                    const int X = min(max(xa + 4 * d, 0), xmax);
+                    v[i] = 0;
+                    if (4 * i < R + 2)   // wave-uniform
+                        v[i] = *reinterpret_cast<const uint32_t *>(a.img + (uint32_t)gy * a.pitch + (uint32_t)X);
+                }
+#pragma unroll
+                for (int i = 0; i < HS_NLD; ++i)
+                    if (4 * i < R + 2) reinterpret_cast<uint32_t *>(tile)[lane + 64 * i] = v[i];
+            } else {
+                const int gxc = min(max(xa + lane, 0), a.w - 1);
+                for (int r = 0; r < R + 2; ++r) {
+                    const int gy = min(max(gy0 - 3 + r, 0), a.h - 1);
+                    tile[r * 64 + lane] = a.img[(size_t)gy * a.pitch + gxc];
+                }
+            }
+            __syncthreads();
+
+            HarrisTile t;
+            t.col = tile + lane;
+            t.gx = xa + lane;
+            t.gy_tile0 = gy0 - 3;
+            t.th = th;
+            t.col_owned = t.gx >= gx0 && t.gx < gx0 + tw;
+            t.col_valid = t.gx >= 2 && t.gx < a.w - 2;
+            t.cell_x = t.col_owned ? (tx + t.gx - gx0) / a.cs : 0;
+            t.cell_row0 = ty;
+            t.keys = keys;
+            HarrisRows st;
+            harris_row<0, 1>(st, a, t, 0);   // warm-up: the pipeline fills over six rows
+            harris_row<1, 1>(st, a, t, 1);
+            harris_row<2, 2>(st, a, t, 2);
+            harris_row<0, 2>(st, a, t, 3);
+            harris_row<1, 3>(st, a, t, 4);
+            harris_row<2, 3>(st, a, t, 5);
+            // steady state, three rows per branch-free iteration; a last partial triple runs on staged
+            // (replicated) rows and is kept out of the keys by the owned-row test
+            for (int r = 6; r < R; r += 3) {
+                harris_row<0, 4>(st, a, t, r);
+                harris_row<1, 4>(st, a, t, r + 1);
+                harris_row<2, 4>(st, a, t, r + 2);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < ncl; i += 64) {
+        const int cx = bx * a.nbx + i % a.nbx, cy = by * a.nby + i / a.nbx;
+        if (cx < a.ncx && cy < a.ncy) a.cell_best[(size_t)cy * a.ncx + cx] = keys[i];
+    }
+}
+
+// ---- FAST: 256-thread workgroup over LDS-staged tiles ------------------------------------------
+__global__ __launch_bounds__(256) void k_fast_cells(CornerArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // carve: keys | score | pixels
     const int ncl = a.nbx * a.nby;
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
     float *sc = reinterpret_cast<float *>(smem + (size_t)((ncl * 8 + 15) & ~15));
-    uint32_t *grad = reinterpret_cast<uint32_t *>(sc + SW * SH);
-    uint8_t *px = reinterpret_cast<uint8_t *>(DET == kHarris ? (void *)(grad + GW * GH) : (void *)grad);
+    uint8_t *px = reinterpret_cast<uint8_t *>(sc + SW * SH);
 
     const int tid = threadIdx.x;
     // each XCD owns a contiguous band of cell blocks (halo rows/columns are shared inside one L2)
@@ -142,48 +319,14 @@ __global__ __launch_bounds__(256) void k_corner_cells(CornerArgs a)
             }
             __syncthreads();
 
-            if (DET == kHarris) {
-                // S2: Sobel gradients on the (tw+4)x(th+4) grid, packed (ix | iy << 16)
-                for (int i = tid; i < GW * GH; i += 256) {
-                    const int r = i / GW, c = i % GW;
-                    if (r < th + 4 && c < tw + 4) {
-                        const uint8_t *p = px + (r + HALO - 2) * PXW + (c + HALO - 2);
-                        const int p00 = p[-PXW - 1], p01 = p[-PXW], p02 = p[-PXW + 1];
-                        const int p10 = p[-1], p12 = p[1];
-                        const int p20 = p[PXW - 1], p21 = p[PXW], p22 = p[PXW + 1];
-                        const int ix = (p02 + 2 * p12 + p22) - (p00 + 2 * p10 + p20);
-                        const int iy = (p20 + 2 * p21 + p22) - (p00 + 2 * p01 + p02);
-                        grad[i] = ((uint32_t)ix & 0xffffu) | ((uint32_t)iy << 16);
-                    }
-                }
-                __syncthreads();
-            }
-
             // S3: score on the (tw+2)x(th+2) grid
             for (int i = tid; i < SW * SH; i += 256) {
                 const int r = i / SW, c = i % SW;
                 if (r < th + 2 && c < tw + 2) {
                     const int gx = gx0 - 1 + c, gy = gy0 - 1 + r;
                     float s = -INFINITY;
-                    if (DET == kHarris) {
-                        if (gx >= 2 && gy >= 2 && gx < a.w - 2 && gy < a.h - 2) {
-                            int sa = 0, sb = 0, sc2 = 0;
-#pragma unroll
-                            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                                for (int dx = 0; dx < 3; ++dx) {
-                                    const uint32_t g = grad[(r + dy) * GW + (c + dx)];
-                                    const int ix = (int)(short)(g & 0xffffu), iy = (int)g >> 16;
-                                    sa += ix * ix;
-                                    sb += ix * iy;
-                                    sc2 += iy * iy;
-                                }
-                            s = harris_r(sa, sb, sc2, a.k);
-                        }
-                    } else {
-                        if (gx >= 3 && gy >= 3 && gx < a.w - 3 && gy < a.h - 3)
-                            s = fast_score(px + (r + HALO - 1) * PXW + (c + HALO - 1), a.fast_n, a.fast_t);
-                    }
+                    if (gx >= 3 && gy >= 3 && gx < a.w - 3 && gy < a.h - 3)
+                        s = fast_score(px + (r + HALO - 1) * PXW + (c + HALO - 1), a.fast_n, a.fast_t);
                     sc[i] = s;
                 }
             }
@@ -340,10 +483,10 @@ __global__ __launch_bounds__(1024) void k_merge_compact(MergeArgs a)
     }
 }
 
-inline void cell_block(uint32_t cs, int &nbx, int &nby)
+inline void cell_block(uint32_t cs, int span_x, int span_y, int &nbx, int &nby)
 {
-    nbx = (int)(TW / cs);
-    nby = (int)(TH / cs);
+    nbx = (int)((uint32_t)span_x / cs);
+    nby = (int)((uint32_t)span_y / cs);
     if (nbx < 1) nbx = 1;
     if (nby < 1) nby = 1;
 }
@@ -366,7 +509,8 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
     a.cs = (int)cs;
     a.ncx = (int)((p.image.width + cs - 1) / cs);
     a.ncy = (int)((p.image.height + cs - 1) / cs);
-    cell_block(cs, a.nbx, a.nby);
+    if (p.detector == kHarris) cell_block(cs, HS_USE, HS_BAND, a.nbx, a.nby);
+    else cell_block(cs, TW, TH, a.nbx, a.nby);
     a.k = p.harris_k; a.thr = p.threshold;
     a.fast_n = (int)p.fast_n; a.fast_t = (int)p.threshold;
     a.cell_best = reinterpret_cast<uint64_t *>(p.scratch);
@@ -374,11 +518,11 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
     const dim3 grid((a.ncx + a.nbx - 1) / a.nbx, (a.ncy + a.nby - 1) / a.nby);
     const size_t keys_b = ((size_t)a.nbx * a.nby * 8 + 15) & ~(size_t)15;
     if (p.detector == kHarris) {
-        const size_t lds = keys_b + SW * SH * 4 + GW * GH * 4 + PXW * PXH;
-        hipLaunchKernelGGL(k_corner_cells<kHarris>, grid, dim3(256), lds, stream, a);
+        const size_t lds = (size_t)HS_R * 64 + keys_b;
+        hipLaunchKernelGGL(k_harris_cells, dim3(grid.x * grid.y), dim3(64), lds, stream, a);
     } else {
         const size_t lds = keys_b + SW * SH * 4 + PXW * PXH;
-        hipLaunchKernelGGL(k_corner_cells<kFast>, grid, dim3(256), lds, stream, a);
+        hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), lds, stream, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -394,3 +538,4 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
 }
 
 }  // namespace vsa
+

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvisualslam_amd.so")
+# VISUALSLAM_AMD_LIB: development override (instrumented builds of the same library)
+LIB_PATH = os.environ.get("VISUALSLAM_AMD_LIB") or os.path.join(_HERE, "lib", "libvisualslam_amd.so")
 
 
 def _fourcc(s):
