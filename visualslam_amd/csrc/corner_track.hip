@@ -133,7 +133,6 @@ __device__ __forceinline__ float right_f(float v) { return __int_as_float(right_
 struct HarrisRows {
     int hd[3], hs[3];             // per pixel row: right-left and left+2*centre+right   (ring, index = row % 3)
     int hxx[3], hxy[3], hyy[3];   // per gradient row: horizontal 3-sums of the gradient products (ring)
-    float s[3];                   // score rows (ring)
 };
 
 // Per-tile constants of the streamed pass
@@ -149,10 +148,10 @@ struct HarrisTile {
 
 // One streamed tile row.  PH = r % 3 (compile time, so the rings live in registers without moves);
 // STAGES = how much of the pipeline is live (warm-up rows run fewer stages).  Pixel row r completes
-// gradient row r-1, tensor/score row r-2 and the NMS of row r-3.  All integer stages are exact, so the
-// separable evaluation order is free; the response is harris_r() as in the oracle.
+// gradient row r-1 and returns the score of row r-2.  All integer stages are exact, so the separable
+// evaluation order is free; the response is harris_r() as in the oracle.
 template <int PH, int STAGES>
-__device__ __forceinline__ void harris_row(HarrisRows &st, const CornerArgs &a, const HarrisTile &t, int r)
+__device__ __forceinline__ float harris_row(HarrisRows &st, const CornerArgs &a, const HarrisTile &t, int r)
 {
     constexpr int P0 = (PH + 1) % 3, P1 = (PH + 2) % 3, P2 = PH;   // ring slots of rows r-2, r-1, r
     {
@@ -161,40 +160,41 @@ __device__ __forceinline__ void harris_row(HarrisRows &st, const CornerArgs &a, 
         st.hd[P2] = rt - l;
         st.hs[P2] = l + 2 * p + rt;
     }
-    if (STAGES >= 2) {   // Sobel at gradient row r-1 -> ring slot P1
+    if (STAGES >= 2) {   // Sobel at gradient row r-1 -> ring slot P1; |ix|,|iy| <= 1020: 24-bit multiplies
         const int ix = st.hd[P0] + 2 * st.hd[P1] + st.hd[P2];
         const int iy = st.hs[P2] - st.hs[P0];
-        const int xx = ix * ix, xy = ix * iy, yy = iy * iy;
+        const int xx = __mul24(ix, ix), xy = __mul24(ix, iy), yy = __mul24(iy, iy);
         st.hxx[P1] = left_i(xx) + xx + right_i(xx);
         st.hxy[P1] = left_i(xy) + xy + right_i(xy);
         st.hyy[P1] = left_i(yy) + yy + right_i(yy);
     }
-    if (STAGES >= 3) {   // score row r-2 -> ring slot P0 (gradient rows r-3, r-2, r-1 = all three ring slots)
+    float s = -INFINITY;
+    if (STAGES >= 3) {   // score of row r-2 (gradient rows r-3, r-2, r-1 = all three ring slots)
         const int gy = t.gy_tile0 + r - 2;
         const float v = harris_r(st.hxx[0] + st.hxx[1] + st.hxx[2], st.hxy[0] + st.hxy[1] + st.hxy[2],
                                  st.hyy[0] + st.hyy[1] + st.hyy[2], a.k);
-        st.s[P0] = (t.col_valid && gy >= 2 && gy < a.h - 2) ? v : -INFINITY;
+        s = (t.col_valid && gy >= 2 && gy < a.h - 2) ? v : -INFINITY;
     }
-    if (STAGES >= 4) {   // NMS row r-3 -> ring slot P2 ; above = r-4 -> P1 ; below = r-2 -> P0
-        const float c = st.s[P2];
-        bool cand = t.col_owned && (r - 6 < t.th) && (c >= a.thr) && (c != -INFINITY);
-        if (__ballot(cand) != 0ull) {   // wave-uniform: candidates are sparse
-            // every lane takes part in the shifts: neighbours are read before any divergence
-            const float up = st.s[P1], dn = st.s[P0];
-            const float ul = left_f(up), ur = right_f(up), cl = left_f(c), cr = right_f(c), dl = left_f(dn),
-                        dr = right_f(dn);
-            cand = cand && !(ul >= c) && !(up >= c) && !(ur >= c) && !(cl >= c) && !(cr > c) && !(dl > c) &&
-                   !(dn > c) && !(dr > c);
-            const int gy = t.gy_tile0 + r - 3;
-            if (cand && a.mask) cand = a.mask[(size_t)gy * a.mask_pitch + t.gx] != 0;
-            if (cand) {
-                const int cell = ((t.cell_row0 + r - 6) / a.cs) * a.nbx + t.cell_x;
-                const uint32_t idx = (uint32_t)gy * (uint32_t)a.w + (uint32_t)t.gx;
-                const uint64_t key = ((uint64_t)orderable(c) << 32) | (uint64_t)(~idx);
-                atomicMax(reinterpret_cast<unsigned long long *>(&t.keys[cell]), (unsigned long long)key);
-            }
-        }
-    }
+    return s;
+}
+
+// is the centre of (up, c, dn) a corner candidate that survives the 3x3 NMS?  `own` already holds
+// ownership and threshold.  Every lane takes part in the shifts (no divergence around them).
+__device__ __forceinline__ bool harris_nms(bool own, float up, float c, float dn)
+{
+    const float ul = left_f(up), ur = right_f(up), cl = left_f(c), cr = right_f(c), dl = left_f(dn), dr = right_f(dn);
+    return own && !(ul >= c) && !(up >= c) && !(ur >= c) && !(cl >= c) && !(cr > c) && !(dl > c) && !(dn > c) &&
+           !(dr > c);
+}
+
+__device__ __forceinline__ void harris_emit(const CornerArgs &a, const HarrisTile &t, int n /* owned row */, float c)
+{
+    const int gy = t.gy_tile0 + 3 + n;
+    if (a.mask && a.mask[(size_t)gy * a.mask_pitch + t.gx] == 0) return;
+    const int cell = ((t.cell_row0 + n) / a.cs) * a.nbx + t.cell_x;
+    const uint32_t idx = (uint32_t)gy * (uint32_t)a.w + (uint32_t)t.gx;
+    const uint64_t key = ((uint64_t)orderable(c) << 32) | (uint64_t)(~idx);
+    atomicMax(reinterpret_cast<unsigned long long *>(&t.keys[cell]), (unsigned long long)key);
 }
 
 __global__ __launch_bounds__(64) void k_harris_cells(CornerArgs a)
@@ -265,14 +265,29 @@ __global__ __launch_bounds__(64) void k_harris_cells(CornerArgs a)
             harris_row<1, 1>(st, a, t, 1);
             harris_row<2, 2>(st, a, t, 2);
             harris_row<0, 2>(st, a, t, 3);
-            harris_row<1, 3>(st, a, t, 4);
-            harris_row<2, 3>(st, a, t, 5);
-            // steady state, three rows per branch-free iteration; a last partial triple runs on staged
-            // (replicated) rows and is kept out of the keys by the owned-row test
+            float sm2 = harris_row<1, 3>(st, a, t, 4);   // scores of tile rows 2 and 3
+            float sm1 = harris_row<2, 3>(st, a, t, 5);
+            // steady state: three rows per branch-free iteration (their chains interleave), then the NMS of
+            // owned rows n, n+1, n+2 (tile rows r-3 .. r-1); candidates are sparse, so one wave-uniform test
+            // covers the triple.  A last partial triple runs on staged rows and fails the owned-row test.
             for (int r = 6; r < R; r += 3) {
-                harris_row<0, 4>(st, a, t, r);
-                harris_row<1, 4>(st, a, t, r + 1);
-                harris_row<2, 4>(st, a, t, r + 2);
+                const int n = r - 6;
+                const float sa = harris_row<0, 3>(st, a, t, r);
+                const float sb = harris_row<1, 3>(st, a, t, r + 1);
+                const float sc = harris_row<2, 3>(st, a, t, r + 2);
+                const bool o0 = t.col_owned && (sm1 >= a.thr) && (sm1 != -INFINITY);
+                const bool o1 = t.col_owned && (n + 1 < th) && (sa >= a.thr) && (sa != -INFINITY);
+                const bool o2 = t.col_owned && (n + 2 < th) && (sb >= a.thr) && (sb != -INFINITY);
+                if (__ballot(o0 || o1 || o2) != 0ull) {
+                    const bool c0 = harris_nms(o0, sm2, sm1, sa);
+                    const bool c1 = harris_nms(o1, sm1, sa, sb);
+                    const bool c2 = harris_nms(o2, sa, sb, sc);
+                    if (c0) harris_emit(a, t, n, sm1);
+                    if (c1) harris_emit(a, t, n + 1, sa);
+                    if (c2) harris_emit(a, t, n + 2, sb);
+                }
+                sm2 = sb;
+                sm1 = sc;
             }
         }
     }
