@@ -390,6 +390,8 @@ struct MergeArgs {
     uint32_t *out_count;
     uint32_t out_capacity;
     size_t *num_corners;
+    uint32_t *out_count_host;
+    uint64_t *num_corners_host;
     uint64_t *cell_best;
     int w, h, cs, ncx, ncy;
 };
@@ -495,6 +497,8 @@ __global__ __launch_bounds__(1024) void k_merge_compact(MergeArgs a)
     if (tid == 0) {
         *a.out_count = min(base, a.out_capacity);
         if (a.num_corners) *a.num_corners = (size_t)base;
+        if (a.out_count_host) *a.out_count_host = min(base, a.out_capacity);
+        if (a.num_corners_host) *a.num_corners_host = (uint64_t)base;
     }
 }
 
@@ -547,6 +551,7 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
     m.tracked_capacity = p.tracked_capacity;
     m.out = p.out; m.out_count = p.out_count; m.out_capacity = p.out_capacity;
     m.num_corners = p.num_corners; m.cell_best = a.cell_best;
+    m.out_count_host = p.out_count_host; m.num_corners_host = p.num_corners_host;
     m.w = a.w; m.h = a.h; m.cs = a.cs; m.ncx = a.ncx; m.ncy = a.ncy;
     hipLaunchKernelGGL(k_merge_compact, dim3(1), dim3(1024), 0, stream, m);
     return hipGetLastError();

@@ -65,6 +65,8 @@ struct CornerTrackParams {
     uint32_t *out_count;
     uint32_t out_capacity;
     size_t *num_corners;          // may be null (device pointer)
+    uint32_t *out_count_host = nullptr;     // optional mirrors in device-visible pinned host memory: the
+    uint64_t *num_corners_host = nullptr;   // merge kernel stores the counts there too (no read-back copy)
     float harris_k;
     float threshold;              // Harris threshold, or (float)FAST threshold
     uint32_t fast_n;
@@ -83,6 +85,7 @@ struct PyrLKParams {
     const void *estimates;        // may alias out
     void *out;
     uint32_t *out_count;          // may alias prev_count's sibling; written with the item count
+    uint32_t *out_count_host = nullptr;   // optional mirror in device-visible pinned host memory
     uint32_t capacity;
     int use_epsilon;
     uint32_t max_iterations;

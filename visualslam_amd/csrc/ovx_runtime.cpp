@@ -92,6 +92,7 @@ struct _vx_array : _vx_reference {
     uint8_t *dev = nullptr;           // items, then a 16-byte tail holding the device-resident u32 count
     uint32_t *dev_count = nullptr;
     size_t num_items = 0;             // host mirror, refreshed after every operation that writes the array
+    uint32_t *count_mirror = nullptr; // set while a graph is enqueued: pinned slot the writing kernel also stores the count to
 };
 
 struct _vx_scalar : _vx_reference {
@@ -123,6 +124,7 @@ struct _vx_node : _vx_reference {
     void *scratch = nullptr;
     size_t scratch_size = 0;
     size_t *dev_num_corners = nullptr;
+    uint64_t *num_corners_mirror = nullptr;   // pinned slot the merge kernel also stores num_corners to (set per enqueue)
     vx_status last_status = VX_SUCCESS;
 };
 
@@ -502,6 +504,7 @@ vx_status do_pyrlk(_vx_pyramid *oldp, _vx_pyramid *newp, _vx_array *oldpts, _vx_
     p.estimates = e->dev;
     p.out = out->dev;
     p.out_count = out->dev_count;
+    p.out_count_host = out->count_mirror;
     p.capacity = (uint32_t)std::min(std::min(oldpts->capacity, out->capacity), e->capacity);
     p.use_epsilon = term != VX_TERM_CRITERIA_ITERATIONS;
     p.max_iterations = term == VX_TERM_CRITERIA_EPSILON ? 100u : iters->v.u32;
@@ -512,7 +515,7 @@ vx_status do_pyrlk(_vx_pyramid *oldp, _vx_pyramid *newp, _vx_array *oldpts, _vx_
 
 vx_status do_corner_track(Detector det, _vx_image *in, _vx_array *out, _vx_image *mask, _vx_array *tracked,
                           float k, float thr, uint32_t fast_n, uint32_t cell, size_t *dev_num_corners,
-                          void *scratch, size_t scratch_size, hipStream_t stream)
+                          uint64_t *num_corners_mirror, void *scratch, size_t scratch_size, hipStream_t stream)
 {
     if (!in || !out) return VX_ERROR_INVALID_PARAMETERS;
     if (in->format != VX_DF_IMAGE_U8) return VX_ERROR_INVALID_FORMAT;
@@ -540,6 +543,8 @@ vx_status do_corner_track(Detector det, _vx_image *in, _vx_array *out, _vx_image
     p.out_count = out->dev_count;
     p.out_capacity = (uint32_t)out->capacity;
     p.num_corners = dev_num_corners;
+    p.out_count_host = out->count_mirror;
+    p.num_corners_host = dev_num_corners ? num_corners_mirror : nullptr;
     p.harris_k = k;
     p.threshold = thr;
     p.fast_n = fast_n;
@@ -598,7 +603,7 @@ vx_status run_node(_vx_node *n, hipStream_t stream)
                                param<_vx_array>(n, 3, VX_TYPE_ARRAY), harris ? scalar_f32(n, 4) : 0.0f,
                                harris ? scalar_f32(n, 5) : (float)scalar_u32(n, 5), harris ? 0u : scalar_u32(n, 4),
                                scalar_u32(n, 6), param<_vx_scalar>(n, 7, VX_TYPE_SCALAR) ? n->dev_num_corners : nullptr,
-                               n->scratch, n->scratch_size, stream);
+                               n->num_corners_mirror, n->scratch, n->scratch_size, stream);
     }
     }
     return VX_ERROR_NOT_IMPLEMENTED;
@@ -720,7 +725,7 @@ vx_status verify_graph(_vx_graph *g)
             g->corner_nodes.push_back(nd);
     }
     if (!ctx->no_device) {
-        const size_t slots = g->written.size() + 2 * g->corner_nodes.size() + 2;
+        const size_t slots = 2 * (g->written.size() + g->corner_nodes.size() + 1);   // 8 bytes per slot
         if (slots > g->pinned_slots) {
             if (g->pinned) (void)hipHostFree(g->pinned);
             g->pinned = nullptr;
@@ -755,6 +760,11 @@ vx_status enqueue_graph(_vx_graph *g)
     }
     if (hipSetDevice(ctx->device) != hipSuccess) return VX_FAILURE;
     g->t0 = std::chrono::steady_clock::now();
+    // the kernels that write an array's count / a node's num_corners also store them to these pinned slots,
+    // so the host has them at stream completion without a read-back copy
+    size_t slot = 0;
+    for (_vx_array *a : g->written) { a->count_mirror = &g->pinned[slot]; slot += 2; }
+    for (_vx_node *n : g->corner_nodes) { n->num_corners_mirror = reinterpret_cast<uint64_t *>(&g->pinned[slot]); slot += 2; }
     for (_vx_node *n : g->order) {
         n->timed = ctx->perf;
         if (n->timed) {
@@ -772,13 +782,7 @@ vx_status enqueue_graph(_vx_graph *g)
             return n->last_status;
         }
     }
-    size_t slot = 0;
-    for (_vx_array *a : g->written)
-        (void)hipMemcpyAsync(&g->pinned[slot++], a->dev_count, 4, hipMemcpyDeviceToHost, g->stream);
-    for (_vx_node *n : g->corner_nodes) {
-        (void)hipMemcpyAsync(&g->pinned[slot], n->dev_num_corners, 8, hipMemcpyDeviceToHost, g->stream);
-        slot += 2;
-    }
+    for (_vx_array *a : g->written) a->count_mirror = nullptr;
     g->scheduled = true;
     g->state = VX_GRAPH_STATE_RUNNING;
     return VX_SUCCESS;
@@ -790,7 +794,7 @@ vx_status finish_graph(_vx_graph *g)
     if (hipStreamSynchronize(g->stream) != hipSuccess) { g->state = VX_GRAPH_STATE_ABANDONED; return VX_FAILURE; }
     g->scheduled = false;
     size_t slot = 0;
-    for (_vx_array *a : g->written) a->num_items = std::min<size_t>(g->pinned[slot++], a->capacity);
+    for (_vx_array *a : g->written) { a->num_items = std::min<size_t>(g->pinned[slot], a->capacity); slot += 2; }
     for (_vx_node *n : g->corner_nodes) {
         uint64_t v;
         memcpy(&v, &g->pinned[slot], 8);
@@ -889,7 +893,7 @@ vx_status immediate_corner(vx_context context, Detector det, vx_image input, vx_
     vx_status s = immediate_scratch(context, need);
     if (s != VX_SUCCESS) return s;
     size_t *dev_nc = num_corners ? reinterpret_cast<size_t *>(static_cast<uint8_t *>(context->scratch) + context->scratch_size) : nullptr;
-    s = do_corner_track(det, in, out, mask, tracked, k, thr, fast_n, cell, dev_nc, context->scratch, context->scratch_size,
+    s = do_corner_track(det, in, out, mask, tracked, k, thr, fast_n, cell, dev_nc, nullptr, context->scratch, context->scratch_size,
                         context->stream);
     if (s != VX_SUCCESS) return s;
     if (dev_nc) (void)hipMemcpyAsync(&context->pinned[2], dev_nc, 8, hipMemcpyDeviceToHost, context->stream);

@@ -48,6 +48,7 @@ struct LKArgs {
     const void *estimates;
     void *out;
     uint32_t *out_count;
+    uint32_t *out_count_host;
     uint32_t capacity;
     int use_eps;
     uint32_t max_it;
@@ -170,7 +171,10 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     uint32_t st_iters = 0;
 #endif
     const uint32_t n = min(*a.prev_count, a.capacity);
-    if (blockIdx.x == 0 && lane == 0) *a.out_count = n;
+    if (blockIdx.x == 0 && lane == 0) {
+        *a.out_count = n;
+        if (a.out_count_host) *a.out_count_host = n;
+    }
     if (blockIdx.x >= n) return;
     // features arrive in detector-cell raster order: consecutive features are image neighbours, so give
     // each XCD a contiguous run of them (their tiles overlap in that XCD's L2)
@@ -397,7 +401,7 @@ hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
     LKArgs a{};
     a.prev = p.prev; a.curr = p.curr; a.item = p.item;
     a.prev_pts = p.prev_pts; a.prev_count = p.prev_count; a.estimates = p.estimates;
-    a.out = p.out; a.out_count = p.out_count; a.capacity = p.capacity;
+    a.out = p.out; a.out_count = p.out_count; a.out_count_host = p.out_count_host; a.capacity = p.capacity;
     a.use_eps = p.use_epsilon; a.max_it = p.max_iterations; a.eps2 = p.epsilon * p.epsilon;
     const int win = (int)p.window;
     a.win = win; a.half = win / 2;

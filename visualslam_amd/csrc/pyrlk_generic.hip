@@ -39,6 +39,7 @@ struct LKArgs {
     const void *estimates;
     void *out;
     uint32_t *out_count;
+    uint32_t *out_count_host;
     uint32_t capacity;
     int use_eps;
     uint32_t max_it;
@@ -88,7 +89,10 @@ __global__ __launch_bounds__(64) void k_pyrlk_generic(LKArgs a)
     const int lane = threadIdx.x;
     const uint32_t pi = blockIdx.x;
     const uint32_t n = min(*a.prev_count, a.capacity);
-    if (pi == 0 && lane == 0) *a.out_count = n;
+    if (pi == 0 && lane == 0) {
+        *a.out_count = n;
+        if (a.out_count_host) *a.out_count_host = n;
+    }
     if (pi >= n) return;
 
     float px, py, ex, ey;
@@ -268,7 +272,7 @@ hipError_t launch_pyrlk_generic(const PyrLKParams &p, hipStream_t stream)
     LKArgs a{};
     a.prev = p.prev; a.curr = p.curr; a.item = p.item;
     a.prev_pts = p.prev_pts; a.prev_count = p.prev_count; a.estimates = p.estimates;
-    a.out = p.out; a.out_count = p.out_count; a.capacity = p.capacity;
+    a.out = p.out; a.out_count = p.out_count; a.out_count_host = p.out_count_host; a.capacity = p.capacity;
     a.use_eps = p.use_epsilon; a.max_it = p.max_iterations; a.eps2 = p.epsilon * p.epsilon;
     const int win = (int)p.window;
     a.win = win; a.half = win / 2;
