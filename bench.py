@@ -127,13 +127,14 @@ def main():
         L = ovx.lib()
         ctx = L.vxCreateContext()
         ovx.check(L.vxGetStatus(ctx), "vxCreateContext")
-        ovx.check(L.vxDirective(ctx, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))   # per-node HIP events
         ring = []
         for f in host_frames:
             img = L.vxCreateImage(ctx, WIDTH, HEIGHT, ovx.VX_DF_IMAGE_RGBX)
             ovx.write_image(img, f)
             ring.append(img)
         trackers = [VxFeatureTracker(ctx, params, WIDTH, HEIGHT, ring[ph], None) for ph in phases]
+        # HIP events around the PyrLK node of stream 0 only (two event records per frame on that graph's stream)
+        ovx.check(L.vxDirective(trackers[0].lk, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
 
         def step(k):
             for trk, ph in zip(trackers, phases):
@@ -214,7 +215,7 @@ def main():
     if rank == 0:
         frames = args.steps * args.streams * world
         fps = frames / elapsed
-        lk_gbs = BYTES_LK / (lk_ms * 1e-3) / 1e9
+        lk_gbs = BYTES_LK / (max(lk_ms, 1e-9) * 1e-3) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "lk_hbm_traffic.json")
         if os.path.exists(tf):

@@ -247,7 +247,9 @@ VX_API_ENTRY vx_context VX_API_CALL vxGetContext(vx_reference reference);
 VX_API_ENTRY vx_status VX_API_CALL vxQueryContext(vx_context context, vx_enum attribute, void *ptr, vx_size size);
 /* nvxio/include/OVX/UtilityOVX.hpp:160-161 */
 VX_API_ENTRY vx_status VX_API_CALL vxGetStatus(vx_reference reference);
-/* demos/feature_tracker/main_feature_tracker.cpp:171 */
+/* demos/feature_tracker/main_feature_tracker.cpp:171.  Given the context (or any other object) the performance
+ * directives switch per-node timing for the whole context, as in the reference; given a vx_node or a vx_graph
+ * they apply to that node / graph only (extension: each timed node costs two HIP events per execution). */
 VX_API_ENTRY vx_status VX_API_CALL vxDirective(vx_reference reference, vx_enum directive);
 /* main_feature_tracker.cpp:178 */
 VX_API_ENTRY void VX_API_CALL vxRegisterLogCallback(vx_context context, vx_log_callback_f callback, vx_bool reentrant);

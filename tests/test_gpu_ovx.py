@@ -182,6 +182,12 @@ def test_perf_counters_num_corners_and_async_graphs(ctx):
     for node in (trackers[0].cvt, trackers[0].pyr, trackers[0].lk, trackers[0].det):
         np_ = ovx.query("vxQueryNode", node, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
         assert np_.num == 1 and 0 < np_.tmp < 50_000_000               # ns (UtilityOVX.cpp:46-68 divides by 1e6 for ms)
+    # directive narrowed to one node: only that node keeps being timed
+    ovx.check(L.vxDirective(ctx, ovx.VX_DIRECTIVE_DISABLE_PERFORMANCE))
+    ovx.check(L.vxDirective(trackers[1].lk, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
+    trackers[1].track(imgs[1], None)
+    assert ovx.query("vxQueryNode", trackers[1].lk, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t).num == 2
+    assert ovx.query("vxQueryNode", trackers[1].det, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t).num == 1
     # num_corners scalar (VX_TYPE_SIZE) through the immediate call
     gray = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
     ovx.check(L.vxuColorConvert(ctx, imgs[0], gray))

@@ -402,25 +402,6 @@ struct KeypointF {
     float error;
 };
 
-__device__ __forceinline__ uint32_t block_scan_flag(bool flag, uint32_t *wave_tot, uint32_t &total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long b = __ballot(flag);
-    const uint32_t pre = __popcll(b & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wave] = __popcll(b);
-    __syncthreads();
-    uint32_t off = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t t = wave_tot[i];
-        off += (i < wave) ? t : 0u;
-        tot += t;
-    }
-    __syncthreads();
-    total = tot;
-    return off + pre;
-}
-
 __device__ __forceinline__ bool tracked_alive(const MergeArgs &a, uint32_t i, float &x, float &y)
 {
     if (a.item == kPoint2f) {
@@ -434,67 +415,139 @@ __device__ __forceinline__ bool tracked_alive(const MergeArgs &a, uint32_t i, fl
     return x >= 0.0f && y >= 0.0f && x <= (float)(a.w - 1) && y <= (float)(a.h - 1);
 }
 
-__global__ __launch_bounds__(1024) void k_merge_compact(MergeArgs a)
+constexpr uint32_t MG_THREADS = 1024;
+constexpr uint32_t MG_B = 8;   // items a thread keeps in registers (fast path: chunks of at most MG_B points and cells)
+
+__device__ __forceinline__ void emit_survivor(const MergeArgs &a, uint32_t pos, uint32_t i, float x, float y)
 {
-    __shared__ uint32_t wave_tot[16];
-    const uint32_t tid = threadIdx.x;
+    if (pos >= a.out_capacity) return;
+    if (a.item == kPoint2f) reinterpret_cast<float2 *>(a.out)[pos] = make_float2(x, y);
+    else reinterpret_cast<KeypointF *>(a.out)[pos] = reinterpret_cast<const KeypointF *>(a.tracked)[i];
+}
+
+__device__ __forceinline__ void emit_corner(const MergeArgs &a, uint32_t pos, uint64_t key)
+{
+    if (pos >= a.out_capacity) return;
+    const uint32_t idx = ~(uint32_t)(key & 0xffffffffull);
+    const float fx = (float)(idx % (uint32_t)a.w), fy = (float)(idx / (uint32_t)a.w);
+    if (a.item == kPoint2f) {
+        reinterpret_cast<float2 *>(a.out)[pos] = make_float2(fx, fy);
+    } else {
+        KeypointF o;
+        o.x = fx; o.y = fy;
+        o.strength = from_orderable((uint32_t)(key >> 32));
+        o.scale = 0.0f; o.orientation = 0.0f;
+        o.tracking_status = 1;
+        o.error = 0.0f;
+        reinterpret_cast<KeypointF *>(a.out)[pos] = o;
+    }
+}
+
+// One pass, one block-wide scan: thread t owns the t-th contiguous chunk of the tracked points and of the
+// cells, so positions follow input order / cell raster order.  The per-thread counts of both lists travel
+// through the scan as the two halves of one 64-bit word.  REG: chunks fit MG_B items, which then stay in
+// registers (all loads of a phase in flight together, nothing re-read).
+template <bool REG>
+__global__ __launch_bounds__(MG_THREADS) void k_merge_compact(MergeArgs a)
+{
+    __shared__ uint64_t wave_tot[MG_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t nt = a.tracked ? min(*a.tracked_count, a.tracked_capacity) : 0u;
     const uint32_t ncells = (uint32_t)a.ncx * (uint32_t)a.ncy;
+    const uint32_t cap_t = a.tracked ? a.tracked_capacity : 0u;
+    // chunk sizes come from the capacity, not the live count, so the register path is a launch-time decision
+    const uint32_t per_t = (cap_t + MG_THREADS - 1) / MG_THREADS, per_c = (ncells + MG_THREADS - 1) / MG_THREADS;
+    const uint32_t t0 = min(tid * per_t, nt), t1 = min(t0 + per_t, nt);
+    const uint32_t c0 = min(tid * per_c, ncells), c1 = min(c0 + per_c, ncells);
 
     // phase 0: cells holding a surviving tracked point emit no new corner
-    for (uint32_t i = tid; i < nt; i += 1024u) {
-        float x, y;
-        if (tracked_alive(a, i, x, y)) {
-            const uint32_t cx = min((uint32_t)x / (uint32_t)a.cs, (uint32_t)a.ncx - 1u);
-            const uint32_t cy = min((uint32_t)y / (uint32_t)a.cs, (uint32_t)a.ncy - 1u);
-            a.cell_best[(size_t)cy * a.ncx + cx] = OCCUPIED;
+    uint32_t n_alive = 0;
+    float px[MG_B], py[MG_B];
+    bool alive[MG_B];
+    if (REG) {
+#pragma unroll
+        for (uint32_t j = 0; j < MG_B; ++j) {
+            const uint32_t i = t0 + j;
+            px[j] = 0.0f; py[j] = 0.0f;
+            alive[j] = (i < t1) && tracked_alive(a, i, px[j], py[j]);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < MG_B; ++j)
+            if (alive[j]) {
+                ++n_alive;
+                const uint32_t cx = min((uint32_t)px[j] / (uint32_t)a.cs, (uint32_t)a.ncx - 1u);
+                const uint32_t cy = min((uint32_t)py[j] / (uint32_t)a.cs, (uint32_t)a.ncy - 1u);
+                a.cell_best[(size_t)cy * a.ncx + cx] = OCCUPIED;
+            }
+    } else {
+        for (uint32_t i = t0; i < t1; ++i) {
+            float x, y;
+            if (tracked_alive(a, i, x, y)) {
+                ++n_alive;
+                const uint32_t cx = min((uint32_t)x / (uint32_t)a.cs, (uint32_t)a.ncx - 1u);
+                const uint32_t cy = min((uint32_t)y / (uint32_t)a.cs, (uint32_t)a.ncy - 1u);
+                a.cell_best[(size_t)cy * a.ncx + cx] = OCCUPIED;
+            }
         }
     }
     __threadfence_block();
     __syncthreads();
 
-    uint32_t base = 0;
-    // phase 1: survivors, input order
-    for (uint32_t i0 = 0; i0 < nt; i0 += 1024u) {
-        const uint32_t i = i0 + tid;
-        float x = 0, y = 0;
-        const bool alive = (i < nt) && tracked_alive(a, i, x, y);
-        uint32_t total;
-        const uint32_t pos = base + block_scan_flag(alive, wave_tot, total);
-        if (alive && pos < a.out_capacity) {
-            if (a.item == kPoint2f) {
-                reinterpret_cast<float2 *>(a.out)[pos] = make_float2(x, y);
-            } else {
-                reinterpret_cast<KeypointF *>(a.out)[pos] = reinterpret_cast<const KeypointF *>(a.tracked)[i];
-            }
+    uint32_t n_new = 0;
+    uint64_t key[MG_B];
+    if (REG) {
+#pragma unroll
+        for (uint32_t j = 0; j < MG_B; ++j) key[j] = (c0 + j < c1) ? a.cell_best[c0 + j] : 0ull;
+#pragma unroll
+        for (uint32_t j = 0; j < MG_B; ++j) n_new += (key[j] != 0ull && key[j] != OCCUPIED) ? 1u : 0u;
+    } else {
+        for (uint32_t c = c0; c < c1; ++c) {
+            const uint64_t k = a.cell_best[c];
+            n_new += (k != 0ull && k != OCCUPIED) ? 1u : 0u;
         }
-        base += total;
     }
-    // phase 2: new corners, cell raster order
-    for (uint32_t c0 = 0; c0 < ncells; c0 += 1024u) {
-        const uint32_t c = c0 + tid;
-        const uint64_t key = (c < ncells) ? a.cell_best[c] : 0ull;
-        const bool has = key != 0ull && key != OCCUPIED;
-        uint32_t total;
-        const uint32_t pos = base + block_scan_flag(has, wave_tot, total);
-        if (has && pos < a.out_capacity) {
-            const uint32_t idx = ~(uint32_t)(key & 0xffffffffull);
-            const float fx = (float)(idx % (uint32_t)a.w), fy = (float)(idx / (uint32_t)a.w);
-            if (a.item == kPoint2f) {
-                reinterpret_cast<float2 *>(a.out)[pos] = make_float2(fx, fy);
-            } else {
-                KeypointF o;
-                o.x = fx; o.y = fy;
-                o.strength = from_orderable((uint32_t)(key >> 32));
-                o.scale = 0.0f; o.orientation = 0.0f;
-                o.tracking_status = 1;
-                o.error = 0.0f;
-                reinterpret_cast<KeypointF *>(a.out)[pos] = o;
-            }
+
+    // block-wide exclusive scan of (n_alive, n_new)
+    const uint64_t v = (uint64_t)n_alive | ((uint64_t)n_new << 32);
+    uint64_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t u = __shfl_up(incl, off);
+        if ((int)lane >= off) incl += u;
+    }
+    if (lane == 63u) wave_tot[wave] = incl;
+    __syncthreads();
+    uint64_t wave_off = 0, total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < MG_THREADS / 64; ++i) {
+        const uint64_t t = wave_tot[i];
+        wave_off += (i < wave) ? t : 0ull;
+        total += t;
+    }
+    const uint64_t excl = wave_off + incl - v;
+    const uint32_t total_alive = (uint32_t)total, total_new = (uint32_t)(total >> 32);
+
+    uint32_t pos = (uint32_t)excl;                              // survivors, input order
+    uint32_t cpos = total_alive + (uint32_t)(excl >> 32);       // new corners, cell raster order
+    if (REG) {
+#pragma unroll
+        for (uint32_t j = 0; j < MG_B; ++j)
+            if (alive[j]) emit_survivor(a, pos++, t0 + j, px[j], py[j]);
+#pragma unroll
+        for (uint32_t j = 0; j < MG_B; ++j)
+            if (key[j] != 0ull && key[j] != OCCUPIED) emit_corner(a, cpos++, key[j]);
+    } else {
+        for (uint32_t i = t0; i < t1; ++i) {
+            float x, y;
+            if (tracked_alive(a, i, x, y)) emit_survivor(a, pos++, i, x, y);
         }
-        base += total;
+        for (uint32_t c = c0; c < c1; ++c) {
+            const uint64_t k = a.cell_best[c];
+            if (k != 0ull && k != OCCUPIED) emit_corner(a, cpos++, k);
+        }
     }
     if (tid == 0) {
+        const uint32_t base = total_alive + total_new;
         *a.out_count = min(base, a.out_capacity);
         if (a.num_corners) *a.num_corners = (size_t)base;
         if (a.out_count_host) *a.out_count_host = min(base, a.out_capacity);
@@ -553,7 +606,10 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
     m.num_corners = p.num_corners; m.cell_best = a.cell_best;
     m.out_count_host = p.out_count_host; m.num_corners_host = p.num_corners_host;
     m.w = a.w; m.h = a.h; m.cs = a.cs; m.ncx = a.ncx; m.ncy = a.ncy;
-    hipLaunchKernelGGL(k_merge_compact, dim3(1), dim3(1024), 0, stream, m);
+    const uint32_t ncells = (uint32_t)a.ncx * (uint32_t)a.ncy;
+    const bool reg = (p.tracked ? p.tracked_capacity : 0u) <= MG_B * MG_THREADS && ncells <= MG_B * MG_THREADS;
+    if (reg) hipLaunchKernelGGL(k_merge_compact<true>, dim3(1), dim3(MG_THREADS), 0, stream, m);
+    else hipLaunchKernelGGL(k_merge_compact<false>, dim3(1), dim3(MG_THREADS), 0, stream, m);
     return hipGetLastError();
 }
 

@@ -121,6 +121,7 @@ struct _vx_node : _vx_reference {
     vx_perf_t perf{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool perf_enabled = false;        // vxDirective on this node alone (extension: narrower than the context-wide switch)
     void *scratch = nullptr;
     size_t scratch_size = 0;
     size_t *dev_num_corners = nullptr;
@@ -134,6 +135,7 @@ struct _vx_graph : _vx_reference {
     vx_enum state = VX_GRAPH_STATE_UNVERIFIED;
     hipStream_t stream = nullptr;
     vx_perf_t perf{};
+    bool perf_enabled = false;            // vxDirective on this graph alone
     std::string options;
     std::vector<_vx_array *> written;     // arrays whose counts are read back after a run
     std::vector<_vx_node *> corner_nodes; // nodes with a num_corners scalar to refresh
@@ -766,7 +768,7 @@ vx_status enqueue_graph(_vx_graph *g)
     for (_vx_array *a : g->written) { a->count_mirror = &g->pinned[slot]; slot += 2; }
     for (_vx_node *n : g->corner_nodes) { n->num_corners_mirror = reinterpret_cast<uint64_t *>(&g->pinned[slot]); slot += 2; }
     for (_vx_node *n : g->order) {
-        n->timed = ctx->perf;
+        n->timed = ctx->perf || g->perf_enabled || n->perf_enabled;
         if (n->timed) {
             if (!n->ev0 && (hipEventCreate(&n->ev0) != hipSuccess || hipEventCreate(&n->ev1) != hipSuccess)) return VX_FAILURE;
             (void)hipEventRecord(n->ev0, g->stream);
@@ -998,9 +1000,16 @@ vx_status vxDirective(vx_reference reference, vx_enum directive)
 {
     if (!valid(reference)) return VX_ERROR_INVALID_REFERENCE;
     _vx_context *ctx = reference->ctx;
+    // performance directives given a node or a graph apply to that object only: timing a node costs two HIP
+    // events on the graph's stream per execution, which an application may not want on every node
+    if (directive == VX_DIRECTIVE_ENABLE_PERFORMANCE || directive == VX_DIRECTIVE_DISABLE_PERFORMANCE) {
+        const bool on = directive == VX_DIRECTIVE_ENABLE_PERFORMANCE;
+        if (reference->type == VX_TYPE_NODE) static_cast<_vx_node *>(reference)->perf_enabled = on;
+        else if (reference->type == VX_TYPE_GRAPH) static_cast<_vx_graph *>(reference)->perf_enabled = on;
+        else ctx->perf = on;
+        return VX_SUCCESS;
+    }
     switch (directive) {
-    case VX_DIRECTIVE_ENABLE_PERFORMANCE: ctx->perf = true; return VX_SUCCESS;
-    case VX_DIRECTIVE_DISABLE_PERFORMANCE: ctx->perf = false; return VX_SUCCESS;
     case VX_DIRECTIVE_ENABLE_LOGGING: ctx->logging = true; return VX_SUCCESS;
     case VX_DIRECTIVE_DISABLE_LOGGING: ctx->logging = false; return VX_SUCCESS;
     default: return VX_ERROR_NOT_SUPPORTED;

@@ -30,6 +30,7 @@ VX_DELAY_TYPE, VX_DELAY_SLOTS = 0x80600, 0x80601
 VX_GRAPH_NUMNODES, VX_GRAPH_PERFORMANCE, VX_GRAPH_STATE = 0x80200, 0x80202, 0x80204
 VX_NODE_PERFORMANCE = 0x80301
 VX_REFERENCE_COUNT, VX_REFERENCE_TYPE = 0x80000, 0x80001
+VX_DIRECTIVE_DISABLE_PERFORMANCE = 0x03002
 VX_DIRECTIVE_ENABLE_PERFORMANCE = 0x03003
 VX_READ_ONLY, VX_WRITE_ONLY, VX_READ_AND_WRITE = 0x11001, 0x11002, 0x11003
 VX_MEMORY_TYPE_HOST, NVX_MEMORY_TYPE_HIP = 0x0E001, 0x0E100
