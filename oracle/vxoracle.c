@@ -372,8 +372,12 @@ uint32_t orc_fast_track(const uint8_t *img, uint32_t pitch, uint32_t w, uint32_t
  * [R] lost POINT2F = (-1,-1) (nvxio/src/OpenGLShaders.hpp:635-641, sfm/SfM.cpp:1535);
  *     KEYPOINTF tracked <=> tracking_status == 255 (object_tracker_keypoint_nvxcu.cpp:1887),
  *     strength carried through (:1912).
- * [P] window offsets -win/2 .. win-1-win/2; coordinates clamp to the image (replicate); Scharr
- *     normalised by 1/32; a level whose window is flat (min-eigenvalue/win^2 < 1e-4 or
+ * [P] window offsets -win/2 .. win-1-win/2; coordinates clamp to the image (replicate).
+ *     Bilinear sampling interpolates along y first, then along x (each an fmaf of the difference).
+ *     The template is resampled at the feature's sub-pixel offset on the window plus a one-pixel
+ *     ring, and its gradients are the Scharr 3x3 derivative (normalised by 1/32) of that resampled
+ *     patch -- Bouguet's formulation; interpolating derivatives of the integer image is the same
+ *     linear operator in exact arithmetic.  A level whose window is flat (min-eigenvalue/win^2 < 1e-4 or
  *     det < FLT_EPSILON) is skipped, and the point is lost when that level is 0; a point whose
  *     window centre strays more than one window outside a level is lost; a point whose final
  *     position leaves [0,w-1]x[0,h-1] is lost; inputs already lost stay lost;
@@ -414,27 +418,11 @@ static inline float pix(const orc_image_t *im, int x, int y)
     return (float)im->data[(size_t)y * im->pitch + x];
 }
 
-static inline float scharr_x(const orc_image_t *im, int x, int y)
-{
-    float t = 3.0f * (pix(im, x + 1, y - 1) - pix(im, x - 1, y - 1));
-    float m = 10.0f * (pix(im, x + 1, y) - pix(im, x - 1, y));
-    float b = 3.0f * (pix(im, x + 1, y + 1) - pix(im, x - 1, y + 1));
-    return (t + m) + b; /* exact: small integers */
-}
-
-static inline float scharr_y(const orc_image_t *im, int x, int y)
-{
-    float l = 3.0f * (pix(im, x - 1, y + 1) - pix(im, x - 1, y - 1));
-    float m = 10.0f * (pix(im, x, y + 1) - pix(im, x, y - 1));
-    float r = 3.0f * (pix(im, x + 1, y + 1) - pix(im, x + 1, y - 1));
-    return (l + m) + r;
-}
-
 static inline float bilerp(float a, float b, float c, float d, float fx, float fy)
-{
-    float top = fmaf(fx, b - a, a);
-    float bot = fmaf(fx, d - c, c);
-    return fmaf(fy, bot - top, top);
+{   /* a b / c d = top-left, top-right / bottom-left, bottom-right */
+    float left = fmaf(fy, c - a, a);
+    float right = fmaf(fy, d - b, b);
+    return fmaf(fx, right - left, left);
 }
 
 #define LK_MAX_WIN 32
@@ -456,6 +444,8 @@ static int lk_track_one(const orc_image_t *prev, const orc_image_t *curr, uint32
     const float inv_area = 1.0f / (float)(2 * win * win);
 
     float Iw[LK_MAX_WIN * LK_MAX_WIN], Ix[LK_MAX_WIN * LK_MAX_WIN], Iy[LK_MAX_WIN * LK_MAX_WIN];
+    float T[(LK_MAX_WIN + 2) * (LK_MAX_WIN + 2)];   /* resampled template: window + one-pixel ring */
+    const int tw = win + 2;
 
     const int top = (int)num_levels - 1;
     float s_top = 1.0f / (float)(1u << top);
@@ -471,16 +461,24 @@ static int lk_track_one(const orc_image_t *prev, const orc_image_t *curr, uint32
         const int ix = (int)fx0 - half, iy = (int)fy0 - half;
         vx = 0.0f; vy = 0.0f;
 
-        /* template window and its gradients */
+        /* template: resample window + ring, then Scharr/32 of the resampled patch.  Separable form
+         * with 3/32 and 10/32 folded in: s = 10/32*mid + 3/32*(up + down) per column, d = down - up,
+         * Ix = s[x+1] - s[x-1], Iy = 10/32*d[x] + 3/32*(d[x-1] + d[x+1]). */
+        for (int ty = 0; ty < tw; ++ty)
+            for (int tx = 0; tx < tw; ++tx) {
+                int x = ix + tx - 1, y = iy + ty - 1;
+                T[ty * tw + tx] = bilerp(pix(I, x, y), pix(I, x + 1, y), pix(I, x, y + 1), pix(I, x + 1, y + 1), ax, ay);
+            }
         for (int wy = 0; wy < win; ++wy)
             for (int wx = 0; wx < win; ++wx) {
-                int x = ix + wx, y = iy + wy;
+                const float *up = &T[wy * tw + wx], *mid = up + tw, *dn = mid + tw;   /* [0..2] = x-1, x, x+1 */
+                const float sl = fmaf(0.3125f, mid[0], 0.09375f * (up[0] + dn[0]));
+                const float sr = fmaf(0.3125f, mid[2], 0.09375f * (up[2] + dn[2]));
+                const float dl = dn[0] - up[0], dc = dn[1] - up[1], dr = dn[2] - up[2];
                 int j = wy * win + wx;
-                Iw[j] = bilerp(pix(I, x, y), pix(I, x + 1, y), pix(I, x, y + 1), pix(I, x + 1, y + 1), ax, ay);
-                Ix[j] = bilerp(scharr_x(I, x, y), scharr_x(I, x + 1, y), scharr_x(I, x, y + 1),
-                               scharr_x(I, x + 1, y + 1), ax, ay) * 0.03125f;
-                Iy[j] = bilerp(scharr_y(I, x, y), scharr_y(I, x + 1, y), scharr_y(I, x, y + 1),
-                               scharr_y(I, x + 1, y + 1), ax, ay) * 0.03125f;
+                Iw[j] = mid[1];
+                Ix[j] = sr - sl;
+                Iy[j] = fmaf(0.3125f, dc, 0.09375f * (dl + dr));
             }
 
         float Gxx, Gxy, Gyy;

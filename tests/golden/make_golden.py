@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/front_end_v1.npz (run once, in the build container, with /root/reference mounted).
+"""Generates tests/golden/front_end_v2.npz (run once, in the build container, with /root/reference mounted).
 
 Inputs are DATA files the reference ships (lena.jpg / baboon.jpg, 512x512 RGB, decoded with PIL and
 cropped to 160x120 to keep the fixture small) plus a seeded synthetic frame.  Outputs are what the
@@ -73,8 +73,8 @@ def main():
         old, cur = trk.track(synth.to_rgbx(synth.gray_frame(base, t, 99)))
         rec.append((len(old), int((cur[:, 0] >= 0).sum()), len(trk.prev_pts), crc(cur), crc(trk.prev_pts)))
     out["seq_record"] = np.array(rec, np.int64)
-    np.savez_compressed(os.path.join(HERE, "front_end_v1.npz"), **out)
-    print("wrote", os.path.join(HERE, "front_end_v1.npz"), os.path.getsize(os.path.join(HERE, "front_end_v1.npz")), "bytes")
+    np.savez_compressed(os.path.join(HERE, "front_end_v2.npz"), **out)
+    print("wrote", os.path.join(HERE, "front_end_v2.npz"), os.path.getsize(os.path.join(HERE, "front_end_v2.npz")), "bytes")
 
 
 if __name__ == "__main__":

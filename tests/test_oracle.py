@@ -1,6 +1,6 @@
 """CPU tests of the oracle (oracle/vxoracle.c): behaviour the reference callers pin, independent
 numpy restatements of the integer stages, analytic properties, and the frozen golden fixture
-(tests/golden/front_end_v1.npz, made by tests/golden/make_golden.py).
+(tests/golden/front_end_v2.npz, made by tests/golden/make_golden.py).
 
 PARITY UNPINNED: the reference holds no golden vector for this path (closed libvisionworks); these
 tests pin the oracle itself."""
@@ -15,7 +15,7 @@ from oracle.pipeline import OracleTracker
 from visualslam_amd import synth
 from visualslam_amd.thin_tracker import Params
 
-GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "front_end_v1.npz"))
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "front_end_v2.npz"))
 
 
 def crc(a):

@@ -96,6 +96,5 @@ struct PyrLKParams {
 // dispatches to the dword-staged fast kernel (pyrlk.hip) when every level is 4-byte aligned,
 // else to the byte-gather fallback (pyrlk_generic.hip); both produce identical results
 hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream);
-hipError_t launch_pyrlk_generic(const PyrLKParams &p, hipStream_t stream);
 
 }  // namespace vsa

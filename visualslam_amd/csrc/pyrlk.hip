@@ -1,25 +1,28 @@
-// pyrlk.hip -- sparse pyramidal Lucas-Kanade optical flow, one wavefront per feature (fast path).
+// pyrlk.hip -- sparse pyramidal Lucas-Kanade optical flow, one wavefront per feature.
 //
 // Reference call sites replaced: vxOpticalFlowPyrLKNode / nvxcuOpticalFlowPyrLK
 // (demos/feature_tracker/feature_tracker.cpp:402-412, demos/feature_tracker_nvxcu/feature_tracker_nvxcu.cpp:297-301,
 // samples/object_tracker_nvxcu/object_tracker_keypoint_nvxcu.cpp:1791-1828).  Semantics and the exact
 // floating-point operation order: oracle/vxoracle.c (lk_track_one) -- results are bit-identical.
 //
-// Design (MI355X, gfx950):
+// Design (MI355X, gfx950).  The kernel is bound by VALU issue, so everything is arranged to spend few
+// vector instructions:
 //   * a 64-lane wave owns one feature for all pyramid levels, coarse to fine; window pixels are
-//     dealt to lanes as (row, segment of `seglen` consecutive pixels), so a lane streams along two
-//     LDS rows and every column it reads serves two neighbouring pixels;
+//     dealt to lanes as (row, segment of `seglen` consecutive pixels), so a lane streams along LDS
+//     rows and every column it touches serves two neighbouring pixels (bilinear sampling is
+//     y-first: one vertical lerp per column, one horizontal lerp per pixel);
 //   * tiles are fetched as ALIGNED DWORDS (4 pixels per lane per load, all loads of a tile issued
 //     back to back into registers), converted once and written to LDS as one ds_write_b128 each;
-//     tiles that poke out of the image are patched per byte with the row's edge pixels (replicate);
+//     which (row, dword) a lane fetches never changes, so that index math is done once per wave.
+//     Tiles that poke out of the image, and pyramids whose base or pitch is not 4-byte aligned,
+//     take per-byte clamped loads into the same registers (replicate border);
 //   * latency hiding inside the wave: the search tile's loads are in flight while the template is
 //     resampled, and the next level's template loads are in flight while this level iterates;
-//   * Scharr gradients are never stored: each lane derives them for its segment from four LDS rows
-//     (exact small integers, so the separable evaluation order is free), then resamples I, Ix, Iy
-//     bilinearly into REGISTERS where they stay for all iterations;
-//   * packed f32 math (v_pk_fma_f32) carries the (top,bottom) row pair and the (Ix,Iy) pair;
-//   * sums are combined by DPP row reductions + 4 readlanes, in the butterfly order the oracle mirrors;
-//   * the 2x2 normal equations are solved in registers, wave-uniformly.
+//   * the template is resampled at the feature's sub-pixel offset and differentiated (Scharr/32,
+//     separable, constants folded) in one streaming pass; I, Ix, Iy stay in REGISTERS for all iterations;
+//   * pair math is scalar f32 (the packed-f32 VALU forms issue slower than two plain ones on gfx950);
+//   * sums are combined by DPP row reductions + two DPP row broadcasts + one readlane, in the
+//     butterfly order the oracle mirrors; the 2x2 normal equations are solved wave-uniformly.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -30,15 +33,6 @@ namespace vsa {
 namespace {
 
 constexpr int LK_MARGIN = 4;  // search tile margin M (pixels) on each side of the window
-
-// A pair of floats handled as two SCALAR f32 operations: on gfx950 the packed-f32 VALU forms (v_pk_fma_f32,
-// v_pk_add_f32, v_pk_mul_f32) issue far slower than two plain v_fma_f32/v_add_f32 (MI355X_MICROARCH.md,
-// constants table), so the pair is kept only as notation and the file is built with -fno-slp-vectorize.
-struct v2f {
-    float x, y;
-};
-__device__ __forceinline__ v2f operator-(v2f a, v2f b) { return { a.x - b.x, a.y - b.y }; }
-__device__ __forceinline__ v2f operator*(v2f a, v2f b) { return { a.x * b.x, a.y * b.y }; }
 
 struct LKArgs {
     PyramidView prev, curr;
@@ -53,7 +47,7 @@ struct LKArgs {
     int use_eps;
     uint32_t max_it;
     float eps2;
-    int win, half, segs, seglen, lanes, lds_floats;
+    int win, half, segs, seglen, lanes;
 };
 
 struct KeypointF {
@@ -66,88 +60,85 @@ struct KeypointF {
 __device__ uint64_t g_lk_stamps[4 * 8192];
 #endif
 
-template <int CTRL>
+template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_mov(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float lane_bcast(float v, int l)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-// Pairwise butterfly (offsets 1,2,4,8,16,32); every lane ends with the same bits.  Within a row of
-// 16 the partner choice of steps 4 and 8 (mirrors) is immaterial because partial sums are already
-// uniform inside each group; rows are combined as (r0+r1)+(r2+r3).  Needs all 64 lanes active.
+// Pairwise butterfly (offsets 1,2,4,8,16,32) read out at lane 63.  Within a row of 16 the partner choice
+// of steps 4 and 8 (mirrors) is immaterial because partial sums are already uniform inside each group;
+// rows are combined as (r0+r1)+(r2+r3): row_bcast:15 adds row 0 into row 1 and row 2 into row 3,
+// row_bcast:31 then adds row 1 into row 3 (float addition commutes exactly).  Needs all 64 lanes active.
 __device__ __forceinline__ float wave_sum(float v)
 {
-    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);   // row_half_mirror
-    v += dpp_mov<0x140>(v);   // row_mirror
-    const float r0 = lane_bcast(v, 0), r1 = lane_bcast(v, 16), r2 = lane_bcast(v, 32), r3 = lane_bcast(v, 48);
-    return (r0 + r1) + (r2 + r3);
+    v += dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
+    v += dpp_mov<0x140, 0xf>(v);   // row_mirror
+    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return { fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y) }; }
-__device__ __forceinline__ v2f splat(float x) { return { x, x }; }
-
-// ---- dword tile staging ----------------------------------------------------------------------
-// A tile of `n` rows x `n` columns with origin (x0,y0) is fetched as n x nd aligned dwords starting
-// at column xa = floor4(x0); LDS image: row r, dword d -> floats [4*(r*nd+d) .. +3], so tile
-// element (r,c) lives at r*4*nd + (x0-xa) + c.
+// ---- tile staging ----------------------------------------------------------------------------
+// A tile with origin (x0,y0) is fetched as rows of ND aligned dwords starting at column
+// xa = floor4(x0).  Slot s = lane + 64*i is (row s / ND, dword s % ND) and lands in LDS as the four floats
+// [4*s .. 4*s+3]: tile element (r,c) lives at r*4*ND + (x0-xa) + c.  Slots past the last tile row
+// fetch (clamped) rows below it; they only fill LDS that nobody interprets.
 template <int NL>
-struct TileLoad {
+struct TileSlots {
+    int row[NL], col4[NL];   // this lane's slots: tile row and byte offset 4*dword inside the row (level-invariant)
+};
+template <int NL>
+struct TileRegs {
     uint32_t v[NL];
-    uint32_t edge[NL];   // row[0] | row[w-1] << 8, only when the tile is not inside the image
 };
 
-template <int NL>
-__device__ __forceinline__ void tile_issue(TileLoad<NL> &t, const uint8_t *img, uint32_t pitch, int w, int h,
-                                           int x0, int y0, int n, int nd, bool inside, int lane)
+template <int NL, int ND>
+__device__ __forceinline__ void tile_slots(TileSlots<NL> &s, int lane)
 {
-    const int xa = x0 & ~3;
-    const float inv_nd = 1.0f / (float)nd;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        // lanes past the end repeat the last dword (same LDS slot, same data): no divergence
-        const int idx = min(lane + 64 * i, n * nd - 1);
-        const int r = (int)(((float)idx + 0.5f) * inv_nd);
-        const int d = idx - r * nd;
-        const int gy = min(max(y0 + r, 0), h - 1);
-        const uint8_t *rowp = img + (uint32_t)gy * pitch;
-        const int X0 = xa + 4 * d;
-        t.edge[i] = 0;
-        if (inside) {   // wave-uniform
-            t.v[i] = *reinterpret_cast<const uint32_t *>(rowp + X0);
-        } else {
-            const int Xl = min(max(X0, 0), (w - 1) & ~3);
-            t.v[i] = *reinterpret_cast<const uint32_t *>(rowp + Xl);
-            t.edge[i] = (uint32_t)rowp[0] | ((uint32_t)rowp[w - 1] << 8);
+        const int idx = lane + 64 * i;
+        s.row[i] = idx / ND;
+        s.col4[i] = 4 * (idx - s.row[i] * ND);
+    }
+}
+
+// fast: the tile's dwords lie inside the row allocation and inside the image columns, and the level is
+// 4-byte aligned -> one dword load per slot.  Otherwise four clamped byte loads (replicate border).
+template <int NL>
+__device__ __forceinline__ void tile_issue(TileRegs<NL> &t, const TileSlots<NL> &s, const uint8_t *img, uint32_t pitch,
+                                           int w, int h, int x0, int y0, bool fast)
+{
+    const int xa = x0 & ~3;
+    if (fast) {   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int gy = min(max(y0 + s.row[i], 0), h - 1);
+            t.v[i] = *reinterpret_cast<const uint32_t *>(img + ((uint32_t)gy * pitch + (uint32_t)(xa + s.col4[i])));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int gy = min(max(y0 + s.row[i], 0), h - 1);
+            const uint8_t *rowp = img + (uint32_t)gy * pitch;
+            const int X = xa + s.col4[i];
+            const uint32_t b0 = rowp[min(max(X, 0), w - 1)], b1 = rowp[min(max(X + 1, 0), w - 1)];
+            const uint32_t b2 = rowp[min(max(X + 2, 0), w - 1)], b3 = rowp[min(max(X + 3, 0), w - 1)];
+            t.v[i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
         }
     }
 }
 
 template <int NL>
-__device__ __forceinline__ void tile_commit(const TileLoad<NL> &t, float *dst, int w, int x0, int n, int nd,
-                                            bool inside, int lane)
+__device__ __forceinline__ void tile_commit(const TileRegs<NL> &t, float *dst, int lane)
 {
-    const int xa = x0 & ~3;
-    const float inv_nd = 1.0f / (float)nd;
+    float4 *d4 = reinterpret_cast<float4 *>(dst) + lane;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-        const int idx = min(lane + 64 * i, n * nd - 1);
         const uint32_t v = t.v[i];
-        uint32_t b0 = v & 0xffu, b1 = (v >> 8) & 0xffu, b2 = (v >> 16) & 0xffu, b3 = v >> 24;
-        if (!inside) {   // wave-uniform
-            const int r = (int)(((float)idx + 0.5f) * inv_nd);
-            const int X0 = xa + 4 * (idx - r * nd);
-            const uint32_t l = t.edge[i] & 0xffu, rr = t.edge[i] >> 8;
-            b0 = (X0 + 0 < 0) ? l : ((X0 + 0 >= w) ? rr : b0);
-            b1 = (X0 + 1 < 0) ? l : ((X0 + 1 >= w) ? rr : b1);
-            b2 = (X0 + 2 < 0) ? l : ((X0 + 2 >= w) ? rr : b2);
-            b3 = (X0 + 3 < 0) ? l : ((X0 + 3 >= w) ? rr : b3);
-        }
-        *reinterpret_cast<float4 *>(dst + 4 * idx) = make_float4((float)b0, (float)b1, (float)b2, (float)b3);
+        d4[64 * i] = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
     }
 }
 
@@ -156,12 +147,14 @@ __device__ __forceinline__ bool tile_inside(int x0, int n, int nd, int w, uint32
     return x0 >= 0 && x0 + n <= w && (x0 & ~3) + 4 * nd <= (int)pitch;
 }
 
-// NSEG: max pixels per lane, WMAX: max window of this instantiation (bounds the unrolled staging)
-template <int NSEG, int WMAX>
+// NSEG: max pixels per lane, WMAX: largest window of this instantiation (fixes LDS strides and slot
+// counts), ALIGNED: every level's base and pitch are multiples of 4
+template <int NSEG, int WMAX, bool ALIGNED>
 __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 {
-    constexpr int NLP = ((WMAX + 3) * ((WMAX + 9) / 4) + 63) / 64;
-    constexpr int NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * ((WMAX + 7 + 2 * LK_MARGIN) / 4) + 63) / 64;
+    constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;   // dwords per tile row
+    constexpr int PS = 4 * NDP, JS = 4 * NDJ;                                              // LDS row strides (floats)
+    constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -198,8 +191,6 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 
     const int win = a.win, half = a.half;
     const int PW = win + 3, JW = win + 1 + 2 * LK_MARGIN;
-    const int NDP = (PW + 6) >> 2, NDJ = (JW + 6) >> 2;
-    const int PS = 4 * NDP, JS = 4 * NDJ;     // LDS row strides (floats)
     float *P = smem;                          // template tile; dead once I/Ix/Iy are in registers
     float *J = smem;                          // search tile (aliases P)
 
@@ -209,9 +200,17 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     int x0 = (lane - row * a.segs) * a.seglen;
     int cnt = min(a.seglen, win - x0);
     if (lane >= a.lanes || cnt < 0) { row = 0; x0 = 0; cnt = 0; }
+    const int lbaseP = row * PS + x0, lbaseJ = row * JS + x0;
 
-    // LDS only ever holds converted pixels or these zeros, so over-reads past a segment are finite
-    for (int i = lane; i < a.lds_floats; i += 64) smem[i] = 0.0f;
+    // LDS only ever holds converted pixels or these zeros (the slack a lane may over-read past its
+    // segment at the end of either tile region), so idle pixels multiply finite values by exact zeros
+    smem[NLP * 256 + lane] = 0.0f;
+    smem[NLJ * 256 + lane] = 0.0f;
+
+    TileSlots<NLP> sp;
+    TileSlots<NLJ> sj;
+    tile_slots<NLP, NDP>(sp, lane);
+    tile_slots<NLJ, NDJ>(sj, lane);
 
     const int top = (int)a.prev.levels - 1;
     const float s_top = 1.0f / (float)(1u << top);
@@ -220,19 +219,17 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     const float inv_area = 1.0f / (float)(2 * win * win);
     const float fw = (float)win;
 
-    float Iw[NSEG];
-    v2f Ig[NSEG];   // (Ix, Iy)
+    float Iw[NSEG], Ix[NSEG], Iy[NSEG];
 
-    TileLoad<NLP> tp;
-    TileLoad<NLJ> tj;
+    TileRegs<NLP> tp;
+    TileRegs<NLJ> tj;
     int p_x0 = 0;
-    bool p_in = false;
     if (ok) {   // template tile of the top level
         p_x0 = (int)floorf(px * s_top) - half - 1;
         const int p_y0 = (int)floorf(py * s_top) - half - 1;
-        p_in = tile_inside(p_x0, PW, NDP, (int)a.prev.width[top], a.prev.pitch[top]);
-        tile_issue(tp, a.prev.ptr[top], a.prev.pitch[top], (int)a.prev.width[top], (int)a.prev.height[top],
-                   p_x0, p_y0, PW, NDP, p_in, lane);
+        const int tw = (int)a.prev.width[top];
+        tile_issue(tp, sp, a.prev.ptr[top], a.prev.pitch[top], tw, (int)a.prev.height[top], p_x0, p_y0,
+                   ALIGNED && tile_inside(p_x0, PW, NDP, tw, a.prev.pitch[top]));
     }
 
     for (int L = top; L >= 0 && ok; --L) {
@@ -247,48 +244,45 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         // search tile around the prediction: its loads fly while the template is resampled
         int jx0 = (int)floorf(ux + gx) - half - LK_MARGIN;
         int jy0 = (int)floorf(uy + gy) - half - LK_MARGIN;
-        bool j_in = tile_inside(jx0, JW, NDJ, lw, jpitch);
-        tile_issue(tj, jp, jpitch, lw, lh, jx0, jy0, JW, NDJ, j_in, lane);
+        tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
 
         __syncthreads();   // previous level's search tile is dead
-        tile_commit(tp, P, lw, p_x0, PW, NDP, p_in, lane);
+        tile_commit(tp, P, lane);
         __syncthreads();
 
-        // template pass: Scharr on the fly from four LDS rows (exact integers), bilinear resample
-        // of I, Ix, Iy into registers.  Streaming over the lane's P columns c = 0 .. cnt+2:
-        // grid column g = c-2 (centre P column c-1) completes at c, window pixel k = c-3 right after.
+        // template pass, streaming over the lane's P columns c = 0 .. NSEG+2 (four rows each):
+        //   v0..v2      vertical lerps of column c            -> resampled rows wy-1, wy, wy+1
+        //   t0..t2      horizontal lerps, resampled column tc = c-1
+        //   sm, df      Scharr column terms of tc (3/32 and 10/32 folded in)
+        //   pixel k = tc-2: Ix = sm[tc] - sm[tc-2], Iy from df[tc-2..tc], I = centre row at tc-1
         float sxx = 0.0f, sxy = 0.0f, syy = 0.0f;
         {
-            const float *q = P + row * PS + (p_x0 & 3) + x0;   // P(row + rr, x0 + c) = q[rr*PS + c]
-            v2f sm0 = splat(0.0f), sm1 = splat(0.0f), df0 = splat(0.0f), df1 = splat(0.0f), ctr1 = splat(0.0f);
-            v2f Ip = splat(0.0f), GXp = splat(0.0f), GYp = splat(0.0f);
+            const float *q = P + lbaseP + (p_x0 & 3);   // P(row + rr, x0 + c) = q[rr*PS + c]
+            float v0p = 0.0f, v1p = 0.0f, v2p = 0.0f;
+            float sm_p = 0.0f, sm_pp = 0.0f, df_p = 0.0f, df_pp = 0.0f, t1_p = 0.0f;
 #pragma unroll
             for (int c = 0; c < NSEG + 3; ++c) {
                 const float p0 = q[c], p1 = q[PS + c], p2 = q[2 * PS + c], p3 = q[3 * PS + c];
-                const v2f lo = { p0, p1 }, mid = { p1, p2 }, hi = { p2, p3 };      // (top, bottom) grid rows
-                const v2f sm = pk_fma(splat(3.0f), hi, pk_fma(splat(10.0f), mid, splat(3.0f) * lo));
-                const v2f df = hi - lo;
-                if (c >= 2) {
-                    const v2f Ic = ctr1;
-                    const v2f GXc = sm - sm0;
-                    const v2f GYc = pk_fma(splat(3.0f), df, pk_fma(splat(10.0f), df1, splat(3.0f) * df0));
+                const float v0 = fmaf(ay, p1 - p0, p0), v1 = fmaf(ay, p2 - p1, p1), v2 = fmaf(ay, p3 - p2, p2);
+                if (c >= 1) {
+                    const float t0 = fmaf(ax, v0 - v0p, v0p), t1 = fmaf(ax, v1 - v1p, v1p), t2 = fmaf(ax, v2 - v2p, v2p);
+                    const float sm = fmaf(0.3125f, t1, 0.09375f * (t0 + t2));
+                    const float df = t2 - t0;
                     if (c >= 3) {
                         const int k = c - 3;
-                        const v2f hi_ = pk_fma(splat(ax), Ic - Ip, Ip);          // (top, bot) horizontal lerps
-                        const v2f hx = pk_fma(splat(ax), GXc - GXp, GXp);
-                        const v2f hy = pk_fma(splat(ax), GYc - GYp, GYp);
-                        Iw[k] = fmaf(ay, hi_.y - hi_.x, hi_.x);
-                        const v2f tops = { hx.x, hy.x }, bots = { hx.y, hy.y };
-                        v2f g = pk_fma(splat(ay), bots - tops, tops) * splat(0.03125f);
-                        if (k >= cnt) g = splat(0.0f);                           // select, not a branch
-                        Ig[k] = g;
-                        sxx = fmaf(g.x, g.x, sxx);
-                        sxy = fmaf(g.x, g.y, sxy);
-                        syy = fmaf(g.y, g.y, syy);
+                        float ix = sm - sm_pp;
+                        float iy = fmaf(0.3125f, df_p, 0.09375f * (df_pp + df));
+                        if (k >= cnt) { ix = 0.0f; iy = 0.0f; }   // selects, not a branch
+                        Iw[k] = t1_p;
+                        Ix[k] = ix;
+                        Iy[k] = iy;
+                        sxx = fmaf(ix, ix, sxx);
+                        sxy = fmaf(ix, iy, sxy);
+                        syy = fmaf(iy, iy, syy);
                     }
-                    Ip = Ic; GXp = GXc; GYp = GYc;
+                    sm_pp = sm_p; sm_p = sm; df_pp = df_p; df_p = df; t1_p = t1;
                 }
-                sm0 = sm1; sm1 = sm; df0 = df1; df1 = df; ctr1 = mid;
+                v0p = v0; v1p = v1; v2p = v2;
             }
         }
         const float Gxx = wave_sum(sxx), Gxy = wave_sum(sxy), Gyy = wave_sum(syy);
@@ -299,9 +293,8 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             p_x0 = (int)floorf(px * sn) - half - 1;
             const int p_y0 = (int)floorf(py * sn) - half - 1;
             const int nw = (int)a.prev.width[L - 1];
-            p_in = tile_inside(p_x0, PW, NDP, nw, a.prev.pitch[L - 1]);
-            tile_issue(tp, a.prev.ptr[L - 1], a.prev.pitch[L - 1], nw, (int)a.prev.height[L - 1],
-                       p_x0, p_y0, PW, NDP, p_in, lane);
+            tile_issue(tp, sp, a.prev.ptr[L - 1], a.prev.pitch[L - 1], nw, (int)a.prev.height[L - 1], p_x0, p_y0,
+                       ALIGNED && tile_inside(p_x0, PW, NDP, nw, a.prev.pitch[L - 1]));
         }
 
         const float det = Gxx * Gyy - Gxy * Gxy;
@@ -317,7 +310,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         const float flw = (float)lw, flh = (float)lh;
 
         __syncthreads();   // every lane is done with P
-        tile_commit(tj, J, lw, jx0, JW, NDJ, j_in, lane);
+        tile_commit(tj, J, lane);
         __syncthreads();
 
         for (uint32_t it = 0; it < a.max_it; ++it) {
@@ -325,35 +318,35 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             if (!(cx > -fw && cy > -fw && cx < flw + fw && cy < flh + fw)) { ok = false; break; }
             const float jfx = floorf(cx), jfy = floorf(cy);
             const float bx = cx - jfx, by = cy - jfy;
-            const int jx = (int)jfx - half, jy = (int)jfy - half;
+            const int jx = __builtin_amdgcn_readfirstlane((int)jfx) - half, jy = __builtin_amdgcn_readfirstlane((int)jfy) - half;
             int ox = jx - jx0, oy = jy - jy0;
             if (ox < 0 || oy < 0 || ox > 2 * LK_MARGIN || oy > 2 * LK_MARGIN) {
                 // walked out of the staged tile: restage around the current position (rare)
                 jx0 = jx - LK_MARGIN; jy0 = jy - LK_MARGIN; ox = LK_MARGIN; oy = LK_MARGIN;
-                j_in = tile_inside(jx0, JW, NDJ, lw, jpitch);
-                tile_issue(tj, jp, jpitch, lw, lh, jx0, jy0, JW, NDJ, j_in, lane);
+                tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
                 __syncthreads();
-                tile_commit(tj, J, lw, jx0, JW, NDJ, j_in, lane);
+                tile_commit(tj, J, lane);
                 __syncthreads();
             }
 #ifdef VSA_LK_STAMPS
             ++st_iters;
 #endif
-            v2f acc = splat(0.0f);
+            float b1 = 0.0f, b2 = 0.0f;
             {
-                const float *jt = J + (oy + row) * JS + (jx0 & 3) + ox + x0;
-                v2f prev = { jt[0], jt[JS] };
+                const float *jt = J + lbaseJ + (oy * JS + (jx0 & 3) + ox);
+                float cp = fmaf(by, jt[JS] - jt[0], jt[0]);
 #pragma unroll
-                for (int k = 0; k < NSEG; ++k) {   // pixels past cnt have Ig = 0 and add exact zeros
-                    const v2f cur = { jt[k + 1], jt[JS + k + 1] };
-                    const v2f h = pk_fma(splat(bx), cur - prev, prev);
-                    const float jv = fmaf(by, h.y - h.x, h.x);
+                for (int k = 0; k < NSEG; ++k) {   // pixels past cnt have Ix = Iy = 0 and add exact zeros
+                    const float cc = fmaf(by, jt[JS + k + 1] - jt[k + 1], jt[k + 1]);
+                    const float jv = fmaf(bx, cc - cp, cp);
                     const float d = Iw[k] - jv;
-                    acc = pk_fma(splat(d), Ig[k], acc);
-                    prev = cur;
+                    b1 = fmaf(d, Ix[k], b1);
+                    b2 = fmaf(d, Iy[k], b2);
+                    cp = cc;
                 }
             }
-            const float b1 = wave_sum(acc.x), b2 = wave_sum(acc.y);
+            b1 = wave_sum(b1);
+            b2 = wave_sum(b2);
             const float etx = (Gyy * b1 - Gxy * b2) * inv_det;
             const float ety = (Gxx * b2 - Gxy * b1) * inv_det;
             vx += etx; vy += ety;
@@ -388,16 +381,27 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 #endif
 }
 
+template <int NSEG, int WMAX>
+hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipStream_t stream)
+{
+    constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;
+    constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
+    constexpr size_t lds = ((NLP > NLJ ? NLP : NLJ) * 256 + 64) * sizeof(float);   // slots + zeroed slack
+    const dim3 grid(capacity), block(64);
+    if (aligned) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false>), grid, block, lds, stream, a);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
 {
     if (p.capacity == 0) return hipSuccess;
-    for (uint32_t l = 0; l < p.prev.levels; ++l) {
-        const bool aligned = ((uintptr_t)p.prev.ptr[l] % 4u == 0) && (p.prev.pitch[l] % 4u == 0) &&
-                             ((uintptr_t)p.curr.ptr[l] % 4u == 0) && (p.curr.pitch[l] % 4u == 0);
-        if (!aligned) return launch_pyrlk_generic(p, stream);
-    }
+    bool aligned = true;
+    for (uint32_t l = 0; l < p.prev.levels; ++l)
+        aligned = aligned && ((uintptr_t)p.prev.ptr[l] % 4u == 0) && (p.prev.pitch[l] % 4u == 0) &&
+                  ((uintptr_t)p.curr.ptr[l] % 4u == 0) && (p.curr.pitch[l] % 4u == 0);
     LKArgs a{};
     a.prev = p.prev; a.curr = p.curr; a.item = p.item;
     a.prev_pts = p.prev_pts; a.prev_count = p.prev_count; a.estimates = p.estimates;
@@ -405,6 +409,7 @@ hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
     a.use_eps = p.use_epsilon; a.max_it = p.max_iterations; a.eps2 = p.epsilon * p.epsilon;
     const int win = (int)p.window;
     a.win = win; a.half = win / 2;
+    // lane map shared with the oracle (lk_map): segs x win lanes of seglen pixels
     int segs = 64 / win;
     if (segs > win) segs = win;
     if (segs < 1) segs = 1;
@@ -412,17 +417,10 @@ hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
     a.segs = (win + a.seglen - 1) / a.seglen;
     a.lanes = a.segs * win;
 
-    const int PW = win + 3, JW = win + 1 + 2 * LK_MARGIN;
-    const size_t fl = (size_t)PW * 4 * ((PW + 6) >> 2);
-    const size_t jl = (size_t)JW * 4 * ((JW + 6) >> 2);
-    a.lds_floats = (int)(fl > jl ? fl : jl) + 32;   // slack: a lane may read NSEG floats past its segment
-    const size_t lds = (size_t)a.lds_floats * sizeof(float);
-    const dim3 grid(p.capacity), block(64);
-    if (win <= 10)      hipLaunchKernelGGL((k_pyrlk<2, 10>),  grid, block, lds, stream, a);
-    else if (win <= 16) hipLaunchKernelGGL((k_pyrlk<4, 16>),  grid, block, lds, stream, a);
-    else if (win <= 21) hipLaunchKernelGGL((k_pyrlk<7, 21>),  grid, block, lds, stream, a);
-    else                hipLaunchKernelGGL((k_pyrlk<16, 32>), grid, block, lds, stream, a);
-    return hipGetLastError();
+    if (win <= 10) return launch_bucket<2, 10>(a, aligned, p.capacity, stream);
+    if (win <= 16) return launch_bucket<4, 16>(a, aligned, p.capacity, stream);
+    if (win <= 21) return launch_bucket<7, 21>(a, aligned, p.capacity, stream);
+    return launch_bucket<16, 32>(a, aligned, p.capacity, stream);
 }
 
 }  // namespace vsa
