@@ -232,7 +232,7 @@ def main():
             "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),
             "frame_algorithmic_GBps": BYTES_FRAME * fps / 1e9,
             "frame_algorithmic_frac_of_hbm_peak": BYTES_FRAME * fps / 1e9 / (HBM_PEAK_GBS * world),
-            "roofline": {"kernel": "k_pyrlk<7,21> (PyrLK, 4096 points x 5 levels, 21x21)", "bound": "hbm",
+            "roofline": {"kernel": "k_pyrlk<7,21,true> (PyrLK, 4096 points x 5 levels, 21x21)", "bound": "hbm",
                          "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "launch_ms": lk_ms, "algorithmic_bytes_per_launch": BYTES_LK},
         }
