@@ -40,7 +40,11 @@ enum nvx_memory_type_e { NVX_MEMORY_TYPE_HIP = 0x0E100 };
 
 /* context creation failures reported through vxGetStatus((vx_reference)context)
  * (the reference's NVX_ERROR_NO_CUDA_GPU, nvxio/src/OVX/UtilityOVX.cpp:92-99) */
-enum nvx_status_e { NVX_ERROR_NO_GPU = -1000, NVX_ERROR_UNSUPPORTED_GPU = -1001 };
+enum nvx_status_e {
+    NVX_ERROR_NO_GPU = -1000, NVX_ERROR_UNSUPPORTED_GPU = -1001,
+    /* the reference's spellings, so its callers (nvxio/src/OVX/UtilityOVX.cpp:92-99) compile unmodified */
+    NVX_ERROR_NO_CUDA_GPU = NVX_ERROR_NO_GPU, NVX_ERROR_UNSUPPORTED_CUDA_GPU = NVX_ERROR_UNSUPPORTED_GPU
+};
 
 /* nvxio/src/OVX/UtilityOVX.cpp:72-88 */
 typedef struct _nvx_module_version_t { vx_uint32 major, minor, patch; vx_char suffix[16]; } nvx_module_version_t;

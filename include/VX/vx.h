@@ -24,6 +24,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <string.h>   /* callers rely on it transitively (demos/feature_tracker/feature_tracker.cpp:436 uses strlen) */
 
 #ifdef __cplusplus
 extern "C" {

@@ -65,7 +65,6 @@ int main(int argc, char **argv)
             else if (k == "verbose") verbose = true;
             else { std::cerr << "unknown key " << k << "\n"; return 2; }
         }
-        ovxio::perfPrinting() = verbose;
 
         std::ifstream in(framesPath, std::ios::binary);
         if (!in) { std::cerr << "cannot open " << framesPath << "\n"; return 3; }
@@ -111,7 +110,7 @@ int main(int argc, char **argv)
             procTimer.tic();
             tracker->track(frame, mask);            // :339
             proc_ms += procTimer.toc();
-            tracker->printPerfs();                  // :347
+            if (verbose) tracker->printPerfs();     // :347
             const std::vector<nvx_point2f_t> prev = readPoints(tracker->getPrevFeatures());
             const std::vector<nvx_point2f_t> curr = readPoints(tracker->getCurrFeatures());
             const vx_uint32 np = (vx_uint32)prev.size(), nc = (vx_uint32)curr.size();

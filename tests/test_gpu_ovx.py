@@ -89,11 +89,56 @@ def test_reference_wrapper_compiled_unmodified_runs(gpu, tmp_path):
     # data/feature_tracker_demo_config.ini values
     cfg = dict(pyr_levels=6, lk_num_iters=5, lk_win_size=6, array_capacity=2000, detector_cell_size=18,
                detector="harris", harris_k=0.04, harris_thresh=2000.0)
-    cmd = [exe, str(fpath), str(w), str(h), str(n), str(opath)] + [f"{k}={v}" for k, v in cfg.items()]
+    cmd = [exe, str(fpath), str(w), str(h), str(n), str(opath)] + [f"{k}={v}" for k, v in cfg.items()] + ["verbose=1"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "Found" in res.stdout                                   # FeatureTrackerImpl::printPerfs ran
     p = Params(pyr_levels=6, lk_num_iters=5, lk_win_size=6, array_capacity=2000, harris_thresh=2000.0)
+    ref = OracleTracker(p)
+    ref.init(frames[0])
+    raw = np.fromfile(opath, np.uint8)
+    off = 0
+    for t in range(1, n):
+        old, cur = ref.track(frames[t])
+        for want in (old, cur):
+            cnt = int(raw[off:off + 4].view(np.uint32)[0]); off += 4
+            got = raw[off:off + 8 * cnt].view(np.float32).reshape(cnt, 2); off += 8 * cnt
+            assert cnt == len(want)
+            assert got.tobytes() == want.tobytes(), f"frame {t}"
+    assert off == raw.size
+
+
+def test_reference_demo_main_compiled_unmodified_runs(gpu, tmp_path):
+    """oracle/_ref/nvx_demo_feature_tracker = the reference's demo itself: main_feature_tracker.cpp,
+    feature_tracker.cpp and the NVXIO core (Application, ConfigParser, OptionHandler, SyncTimer, UtilityOVX ...)
+    compiled unmodified from where they lie, plus shim/headless_io.cpp for the frame source / render factories.
+    It parses its own ini format and command line, and runs its own frame loop against libvisualslam_amd."""
+    import shutil
+    exe = os.path.join(ROOT, "oracle", "_ref", "nvx_demo_feature_tracker")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/nvx_demo_feature_tracker not built (needs /root/reference at build time)")
+    # nvxio::Application locates its data directory relative to a .../bin/ directory (Application.cpp:316-350)
+    (tmp_path / "bin").mkdir()
+    (tmp_path / "data").mkdir()
+    run_exe = tmp_path / "bin" / "nvx_demo_feature_tracker"
+    shutil.copy(exe, run_exe)
+    w, h, n = 640, 480, 7
+    frames = _frames(w, h, n, seed=31)
+    fpath, opath, cfg = tmp_path / "frames.rgbx", tmp_path / "out.bin", tmp_path / "data" / "feature_tracker_demo_config.ini"
+    with open(fpath, "wb") as f:
+        for fr in frames:
+            f.write(fr.tobytes())
+    cfg.write_text("pyr_levels = 4\nlk_num_iters = 5\nlk_win_size = 10\n\narray_capacity = 1500\ndetector_cell_size = 18\n"
+                   "detector = fast\n\nharris_k = 0.04\nharris_thresh = 2000.0\n\nfast_type = 9\nfast_thresh = 25\n")
+    env = dict(os.environ, VSA_HEADLESS_FRAMES=str(n - 1), VSA_HEADLESS_OUT=str(opath),
+               LD_LIBRARY_PATH=os.path.join(ROOT, "visualslam_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    cmd = [str(run_exe), f"--source=rawrgbx://{fpath}?width={w}&height={h}", "--nvxio_fps_limit=1000"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env)
+    if res.returncode != 0 and "nvxio_fps_limit" in (res.stdout + res.stderr):
+        res = subprocess.run(cmd[:2], capture_output=True, text=True, timeout=180, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "Graph Time" in res.stdout                               # ovxio::printPerf (UtilityOVX.cpp:46-68) via printPerfs()
+    p = Params(pyr_levels=4, lk_num_iters=5, lk_win_size=10, array_capacity=1500, use_harris_detector=False)
     ref = OracleTracker(p)
     ref.init(frames[0])
     raw = np.fromfile(opath, np.uint8)
