@@ -46,6 +46,30 @@ def test_sequence_matches_oracle(gpu, harris, win, levels):
         assert len(cur) > 500 and (cur[:, 0] >= 0).mean() > 0.8
 
 
+@pytest.mark.parametrize("name,w,h,levels,harris,cap,win", [
+    ("C2 1080p / 5 levels / Harris / 4096 features / 21x21", 1920, 1080, 5, True, 4096, 21),
+    ("C3 4K / 7 levels / FAST-9 t=25 / 10000 features / 21x21", 3840, 2160, 7, False, 10000, 21)])
+def test_baseline_configs_full_size(gpu, name, w, h, levels, harris, cap, win):
+    """BASELINE.json configs[1] and configs[2] at their full sizes, two tracked frames, bit for bit
+    (the OpenMP build of the oracle keeps this to a few seconds)."""
+    p = Params(pyr_levels=levels, lk_win_size=win, use_harris_detector=harris, array_capacity=cap,
+               harris_thresh=100.0, fast_type=9, fast_thresh=25)
+    frames = _frames(w, h, 3, seed=1234)
+    dev = [DeviceImage(w, h, nvxcu.NVXCU_DF_IMAGE_RGBX).upload(f) for f in frames]
+    trk = ThinFeatureTracker(p, w, h)
+    ref = OracleTracker(p, omp=True)
+    trk.init(dev[0].desc)
+    ref.init(frames[0])
+    for t in (1, 2):
+        trk.track(dev[t].desc)
+        trk.synchronize()
+        old, cur = ref.track(frames[t])
+        assert trk.prev_features().tobytes() == old.tobytes(), f"{name}: frame {t} prev"
+        assert trk.curr_features().tobytes() == cur.tobytes(), f"{name}: frame {t} tracked"
+        assert trk.curr_pts.download().tobytes() == ref.prev_pts.tobytes(), f"{name}: frame {t} merged"
+        assert len(cur) == cap and (cur[:, 0] >= 0).mean() > 0.9
+
+
 def test_u8_input_and_no_mask(gpu):
     w, h = 320, 240
     p = Params(pyr_levels=3, lk_win_size=7, array_capacity=500)
