@@ -183,3 +183,27 @@ def optical_flow_pyr_lk(prev_pyr, curr_pyr, prev_pts, estimates=None, terminatio
                                      out.ctypes.data, len(prev_pts), termination, epsilon,
                                      num_iterations, window, sum_mode)
     return out
+
+
+def homography_hypotheses(confidence=0.995, outlier_ratio=0.45, max_estimate_iters=2000):
+    f = lib().orc_homography_hypotheses
+    f.restype, f.argtypes = C.c_uint32, [C.c_float, C.c_float, C.c_uint32]
+    return int(f(confidence, outlier_ratio, max_estimate_iters))
+
+
+def find_homography(src, dst, threshold=3.0, max_estimate_iters=2000, max_refine_iters=10, confidence=0.995,
+                    outlier_ratio=0.45):
+    """nvxFindHomographyNode (RANSAC) as the oracle defines it.  src/dst: (n,2) float32.  Returns
+    (matrix data as the API hands it out = H transposed, 3x3 float32; mask uint8 (n,); inlier count)."""
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    dst = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
+    n = min(len(src), len(dst))
+    H = np.zeros(9, np.float32)
+    mask = np.zeros(max(n, 1), np.uint8)
+    f = lib().orc_find_homography
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
+                  C.c_void_p, C.c_void_p]
+    cnt = f(src.ctypes.data, dst.ctypes.data, n, threshold, max_estimate_iters, max_refine_iters, confidence,
+            outlier_ratio, H.ctypes.data, mask.ctypes.data)
+    return H.reshape(3, 3), mask[:n], int(cnt)

@@ -91,6 +91,14 @@ void orc_optical_flow_pyr_lk(const orc_image_t *prev_levels, const orc_image_t *
                              int termination, float epsilon, uint32_t num_iterations,
                              uint32_t window, int sum_mode);
 
+/* nvxFindHomographyNode (RANSAC): demos/video_stabilizer/stabilizer.cpp:264-273, SfM.cpp:1576-1578.
+ * src/dst: n x {f32 x,y}; H_out: 9 floats, element [3*c + r] = H[r][c] (homography_filter_node.cpp:87-91);
+ * mask: n bytes, 255 = inlier.  Returns the inlier count.  Policies: vxoracle_homography.c. */
+uint32_t orc_find_homography(const float *src, const float *dst, uint32_t n, float threshold,
+                             uint32_t max_estimate_iters, uint32_t max_refine_iters, float confidence,
+                             float outlier_ratio, float *H_out, uint8_t *mask);
+uint32_t orc_homography_hypotheses(float confidence, float outlier_ratio, uint32_t max_estimate_iters);
+
 #ifdef __cplusplus
 }
 #endif
