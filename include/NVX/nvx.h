@@ -73,6 +73,24 @@ VX_API_ENTRY vx_status VX_API_CALL nvxuFastTrack(vx_context context, vx_image in
                                                  vx_array tracked_points, vx_uint32 type, vx_uint32 threshold,
                                                  vx_uint32 cell_size, vx_scalar num_corners);
 
+/* demos/video_stabilizer/stabilizer.cpp:264-273, VisionWorks-SFM-0.90-Samples/samples/sfm/SfM.cpp:1576-1578.
+ * Homography between two NVX_TYPE_POINT2F arrays (RANSAC); correspondences with a negative coordinate (PyrLK's lost
+ * points) are ignored.  `homography`: 3x3 VX_TYPE_FLOAT32, stored so that the consumers' transpose gives x' ~ H x
+ * (homography_filter_node.cpp:87-91).  `mask` (optional): VX_TYPE_UINT8 array, one item per correspondence, non-zero =
+ * inlier.  Parameter indices: 0 src, 1 dst, 2 homography, 3 method, 4 threshold, 5 maxEstimateIters, 6 maxRefineIters,
+ * 7 confidence, 8 outlierRatio, 9 mask. */
+enum nvx_find_homography_method_e {
+    NVX_FIND_HOMOGRAPHY_METHOD_RANSAC = 0x80300, NVX_FIND_HOMOGRAPHY_METHOD_LMEDS   /* only RANSAC is implemented */
+};
+VX_API_ENTRY vx_node VX_API_CALL nvxFindHomographyNode(vx_graph graph, vx_array srcPoints, vx_array dstPoints,
+                                                       vx_matrix homography, vx_enum method, vx_float32 threshold,
+                                                       vx_uint32 maxEstimateIters, vx_uint32 maxRefineIters,
+                                                       vx_float32 confidence, vx_float32 outlierRatio, vx_array mask);
+VX_API_ENTRY vx_status VX_API_CALL nvxuFindHomography(vx_context context, vx_array srcPoints, vx_array dstPoints,
+                                                      vx_matrix homography, vx_enum method, vx_float32 threshold,
+                                                      vx_uint32 maxEstimateIters, vx_uint32 maxRefineIters,
+                                                      vx_float32 confidence, vx_float32 outlierRatio, vx_array mask);
+
 /* demos/video_stabilizer/stabilizer.cpp:245 */
 VX_API_ENTRY vx_node VX_API_CALL nvxCopyImageNode(vx_graph graph, vx_image src, vx_image dst);
 VX_API_ENTRY vx_status VX_API_CALL nvxuCopyImage(vx_context context, vx_image src, vx_image dst);

@@ -58,6 +58,7 @@ typedef enum _vx_bool_e { vx_false_e = 0, vx_true_e = 1 } vx_bool;
 /* ---- opaque objects ---------------------------------------------------------------------- */
 typedef struct _vx_reference *vx_reference;
 typedef struct _vx_context   *vx_context;
+typedef struct _vx_matrix    *vx_matrix;
 typedef struct _vx_graph     *vx_graph;
 typedef struct _vx_node      *vx_node;
 typedef struct _vx_image     *vx_image;
@@ -263,6 +264,9 @@ VX_API_ENTRY vx_status VX_API_CALL vxReleaseReference(vx_reference *ref);
 /* ---- image ------------------------------------------------------------------------------- */
 /* feature_tracker.cpp:319, main_feature_tracker.cpp:233-234 (U8 and RGBX, pitch-linear in HBM) */
 VX_API_ENTRY vx_image VX_API_CALL vxCreateImage(vx_context context, vx_uint32 width, vx_uint32 height, vx_df_image color);
+/* demos/video_stabilizer/stabilizer.cpp:237: graph-internal image; width = height = 0 are inferred from the node that
+ * writes it at vxVerifyGraph */
+VX_API_ENTRY vx_image VX_API_CALL vxCreateVirtualImage(vx_graph graph, vx_uint32 width, vx_uint32 height, vx_df_image color);
 VX_API_ENTRY vx_status VX_API_CALL vxReleaseImage(vx_image *image);
 /* feature_tracker.cpp:135-137,192-194 */
 VX_API_ENTRY vx_status VX_API_CALL vxQueryImage(vx_image image, vx_enum attribute, void *ptr, vx_size size);
@@ -285,9 +289,26 @@ VX_API_ENTRY vx_status VX_API_CALL vxQueryPyramid(vx_pyramid pyr, vx_enum attrib
 /* feature_tracker.cpp:362 -- returns an OWNED reference (released at :448) aliasing the level's memory */
 VX_API_ENTRY vx_image VX_API_CALL vxGetPyramidLevel(vx_pyramid pyr, vx_uint32 index);
 
+/* ---- matrix ------------------------------------------------------------------------------- */
+enum vx_matrix_attribute_e {
+    VX_MATRIX_TYPE = 0x80B00, VX_MATRIX_ROWS, VX_MATRIX_COLUMNS, VX_MATRIX_SIZE,
+    VX_MATRIX_ATTRIBUTE_TYPE = VX_MATRIX_TYPE, VX_MATRIX_ATTRIBUTE_ROWS = VX_MATRIX_ROWS,
+    VX_MATRIX_ATTRIBUTE_COLUMNS = VX_MATRIX_COLUMNS, VX_MATRIX_ATTRIBUTE_SIZE = VX_MATRIX_SIZE
+};
+/* demos/video_stabilizer/stabilizer.cpp:262,289; homography_filter_node.cpp:50-51 */
+VX_API_ENTRY vx_matrix VX_API_CALL vxCreateMatrix(vx_context context, vx_enum data_type, vx_size columns, vx_size rows);
+VX_API_ENTRY vx_status VX_API_CALL vxReleaseMatrix(vx_matrix *mat);
+VX_API_ENTRY vx_status VX_API_CALL vxQueryMatrix(vx_matrix mat, vx_enum attribute, void *ptr, vx_size size);
+VX_API_ENTRY vx_status VX_API_CALL vxCopyMatrix(vx_matrix mat, void *user_ptr, vx_enum usage, vx_enum user_mem_type);
+VX_API_ENTRY vx_status VX_API_CALL vxReadMatrix(vx_matrix mat, void *array);          /* OpenVX 1.0 */
+VX_API_ENTRY vx_status VX_API_CALL vxWriteMatrix(vx_matrix mat, const void *array);   /* OpenVX 1.0 */
+
 /* ---- array -------------------------------------------------------------------------------- */
 /* feature_tracker.cpp:298,308 */
 VX_API_ENTRY vx_array VX_API_CALL vxCreateArray(vx_context context, vx_enum item_type, vx_size capacity);
+/* demos/video_stabilizer/stabilizer.cpp:254,263: graph-internal array (same object kind; access from the host is
+ * not restricted here) */
+VX_API_ENTRY vx_array VX_API_CALL vxCreateVirtualArray(vx_graph graph, vx_enum item_type, vx_size capacity);
 VX_API_ENTRY vx_status VX_API_CALL vxReleaseArray(vx_array *arr);
 /* feature_tracker.cpp:240, nvxio/src/OVX/Private/TypesOVX.cpp:88-97 */
 VX_API_ENTRY vx_status VX_API_CALL vxQueryArray(vx_array arr, vx_enum attribute, void *ptr, vx_size size);

@@ -93,8 +93,28 @@ struct PyrLKParams {
     uint32_t window;
 };
 
-// dispatches to the dword-staged fast kernel (pyrlk.hip) when every level is 4-byte aligned,
-// else to the byte-gather fallback (pyrlk_generic.hip); both produce identical results
+// one kernel (pyrlk.hip): aligned dword staging when every level is 4-byte aligned, per-byte clamped loads
+// otherwise; both produce identical results
 hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream);
+
+// nvxFindHomography (RANSAC) on POINT2F correspondences (homography.hip; semantics: oracle/vxoracle_homography.c)
+struct HomographyParams {
+    const void *src, *dst;                // POINT2F arrays
+    const uint32_t *src_count, *dst_count;
+    uint32_t src_capacity, dst_capacity;
+    float threshold;
+    uint32_t hypotheses;                  // homography_hypotheses(confidence, outlier_ratio, max_estimate_iters)
+    uint32_t max_refine_iters;
+    float *matrix;                        // 9 floats, element [3*c + r] = H[r][c]
+    float *matrix_host = nullptr;         // optional mirror in device-visible pinned host memory
+    uint8_t *mask;                        // may be null; one byte per correspondence, 255 = inlier
+    uint32_t *mask_count;                 // item count of the mask array (device), may be null iff mask is
+    uint32_t *mask_count_host = nullptr;
+    uint32_t mask_capacity;
+    void *scratch;                        // homography_scratch_bytes(hypotheses) bytes, 8-byte aligned
+};
+uint32_t homography_hypotheses(float confidence, float outlier_ratio, uint32_t max_estimate_iters);
+size_t homography_scratch_bytes(uint32_t hypotheses);
+hipError_t launch_find_homography(const HomographyParams &p, hipStream_t stream);
 
 }  // namespace vsa

@@ -72,6 +72,7 @@ struct _vx_context : _vx_reference {
 };
 
 struct _vx_image : _vx_reference {
+    bool is_virtual = false;          // vxCreateVirtualImage: dimensions may be 0 until vxVerifyGraph infers them
     uint32_t width = 0, height = 0, bpp = 1;
     vx_df_image format = VX_DF_IMAGE_VIRT;
     uint8_t *dev = nullptr;
@@ -102,12 +103,20 @@ struct _vx_scalar : _vx_reference {
             vx_bool b; } v{};
 };
 
+struct _vx_matrix : _vx_reference {
+    vx_enum data_type = 0;
+    size_t cols = 0, rows = 0;
+    std::vector<uint8_t> host;        // the values as the application sees them (row-major)
+    void *dev = nullptr;              // device copy, allocated when a node first writes or reads it
+    float *mirror = nullptr;          // set while a graph is enqueued: pinned slots the writing kernel also stores to
+};
+
 struct _vx_delay : _vx_reference {
     vx_enum slot_type = 0;
     std::vector<_vx_reference *> slots;   // slots[i] <-> index -i
 };
 
-enum KernelKind { K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE };
+enum KernelKind { K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE, K_FIND_HOMOGRAPHY };
 
 struct ParamSpec { vx_enum dir; vx_enum type; bool optional; };
 
@@ -139,6 +148,7 @@ struct _vx_graph : _vx_reference {
     std::string options;
     std::vector<_vx_array *> written;     // arrays whose counts are read back after a run
     std::vector<_vx_node *> corner_nodes; // nodes with a num_corners scalar to refresh
+    std::vector<_vx_matrix *> matrices;   // matrices written by nodes: values come back through pinned slots
     uint32_t *pinned = nullptr;           // count read-back staging (pinned)
     size_t pinned_slots = 0;
     bool scheduled = false;
@@ -283,6 +293,11 @@ void destroy(_vx_reference *r)
         for (auto *s : d->slots) { s->delay = nullptr; release_ref(s); }
         break;
     }
+    case VX_TYPE_MATRIX: {
+        auto *m = static_cast<_vx_matrix *>(r);
+        if (m->dev) (void)hipFree(m->dev);
+        break;
+    }
     case VX_TYPE_NODE: {
         auto *n = static_cast<_vx_node *>(r);
         for (auto *p : n->params) release_ref(p);
@@ -313,6 +328,7 @@ void destroy(_vx_reference *r)
     case VX_TYPE_ARRAY: delete static_cast<_vx_array *>(r); break;
     case VX_TYPE_SCALAR: delete static_cast<_vx_scalar *>(r); break;
     case VX_TYPE_DELAY: delete static_cast<_vx_delay *>(r); break;
+    case VX_TYPE_MATRIX: delete static_cast<_vx_matrix *>(r); break;
     case VX_TYPE_NODE: delete static_cast<_vx_node *>(r); break;
     case VX_TYPE_GRAPH: delete static_cast<_vx_graph *>(r); break;
     default: delete r; break;
@@ -393,6 +409,25 @@ _vx_scalar *new_scalar(_vx_context *ctx, vx_enum type, const void *ptr)
     if (ptr) memcpy(&s->v, ptr, item_size_of(type));
     track(ctx, s);
     return s;
+}
+
+_vx_matrix *new_matrix(_vx_context *ctx, vx_enum data_type, size_t cols, size_t rows)
+{
+    auto *m = new _vx_matrix();
+    m->type = VX_TYPE_MATRIX;
+    m->ctx = ctx;
+    m->data_type = data_type;
+    m->cols = cols; m->rows = rows;
+    m->host.assign(cols * rows * item_size_of(data_type), 0);
+    track(ctx, m);
+    return m;
+}
+
+vx_status ensure_matrix(_vx_matrix *m)
+{
+    if (m->dev) return VX_SUCCESS;
+    if (m->ctx->no_device) return (vx_status)NVX_ERROR_NO_GPU;
+    return hipMalloc(&m->dev, m->host.size() + 16) == hipSuccess ? VX_SUCCESS : VX_ERROR_NO_MEMORY;
 }
 
 // ---- pinned count read-back --------------------------------------------------------------------
@@ -555,6 +590,39 @@ vx_status do_corner_track(Detector det, _vx_image *in, _vx_array *out, _vx_image
     return hip_status(launch_corner_track(p, stream));
 }
 
+vx_status do_find_homography(_vx_array *src, _vx_array *dst, _vx_matrix *mat, vx_enum method, float threshold,
+                             uint32_t max_estimate, uint32_t max_refine, float confidence, float outlier_ratio,
+                             _vx_array *mask, void *scratch, size_t scratch_size, hipStream_t stream)
+{
+    if (!src || !dst || !mat) return VX_ERROR_INVALID_PARAMETERS;
+    if (method != NVX_FIND_HOMOGRAPHY_METHOD_RANSAC) return VX_ERROR_NOT_SUPPORTED;
+    if (src->item_type != NVX_TYPE_POINT2F || dst->item_type != NVX_TYPE_POINT2F) return VX_ERROR_INVALID_TYPE;
+    if (mat->data_type != VX_TYPE_FLOAT32 || mat->cols != 3 || mat->rows != 3) return VX_ERROR_INVALID_DIMENSION;
+    if (mask && mask->item_type != VX_TYPE_UINT8) return VX_ERROR_INVALID_TYPE;
+    if (!(threshold > 0.0f)) return VX_ERROR_INVALID_VALUE;
+    HomographyParams p{};
+    p.hypotheses = homography_hypotheses(confidence, outlier_ratio, max_estimate);
+    if (scratch_size < homography_scratch_bytes(p.hypotheses)) return VX_ERROR_NO_MEMORY;
+    vx_status s = ensure_array(src);
+    if (s == VX_SUCCESS) s = ensure_array(dst);
+    if (s == VX_SUCCESS && mask) s = ensure_array(mask);
+    if (s == VX_SUCCESS) s = ensure_matrix(mat);
+    if (s != VX_SUCCESS) return s;
+    p.src = src->dev; p.dst = dst->dev;
+    p.src_count = src->dev_count; p.dst_count = dst->dev_count;
+    p.src_capacity = (uint32_t)src->capacity; p.dst_capacity = (uint32_t)dst->capacity;
+    p.threshold = threshold;
+    p.max_refine_iters = max_refine;
+    p.matrix = static_cast<float *>(mat->dev);
+    p.matrix_host = mat->mirror;
+    p.mask = mask ? mask->dev : nullptr;
+    p.mask_count = mask ? mask->dev_count : nullptr;
+    p.mask_count_host = mask ? mask->count_mirror : nullptr;
+    p.mask_capacity = mask ? (uint32_t)mask->capacity : 0;
+    p.scratch = scratch;
+    return hip_status(launch_find_homography(p, stream));
+}
+
 template <typename T>
 T *param(_vx_node *n, size_t i, vx_enum type) { return i < n->params.size() ? as<T>(n->params[i], type) : nullptr; }
 
@@ -581,9 +649,32 @@ vx_status node_scratch(_vx_node *n)
     return VX_SUCCESS;
 }
 
+vx_status homography_node_scratch(_vx_node *n)
+{
+    const size_t need = homography_scratch_bytes(homography_hypotheses(scalar_f32(n, 7), scalar_f32(n, 8), scalar_u32(n, 5)));
+    if (need > n->scratch_size) {
+        if (n->ctx->no_device) return (vx_status)NVX_ERROR_NO_GPU;
+        if (n->scratch) (void)hipFree(n->scratch);
+        n->scratch = nullptr;
+        n->scratch_size = 0;
+        if (hipMalloc(&n->scratch, need) != hipSuccess) return VX_ERROR_NO_MEMORY;
+        n->scratch_size = need;
+    }
+    return VX_SUCCESS;
+}
+
 vx_status run_node(_vx_node *n, hipStream_t stream)
 {
     switch (n->kind) {
+    case K_FIND_HOMOGRAPHY: {
+        vx_status s = homography_node_scratch(n);
+        if (s != VX_SUCCESS) return s;
+        auto *m = param<_vx_scalar>(n, 3, VX_TYPE_SCALAR);
+        return do_find_homography(param<_vx_array>(n, 0, VX_TYPE_ARRAY), param<_vx_array>(n, 1, VX_TYPE_ARRAY),
+                                  param<_vx_matrix>(n, 2, VX_TYPE_MATRIX), m ? m->v.e : 0, scalar_f32(n, 4), scalar_u32(n, 5),
+                                  scalar_u32(n, 6), scalar_f32(n, 7), scalar_f32(n, 8), param<_vx_array>(n, 9, VX_TYPE_ARRAY),
+                                  n->scratch, n->scratch_size, stream);
+    }
     case K_COLOR_CONVERT:
         return do_color_convert(param<_vx_image>(n, 0, VX_TYPE_IMAGE), param<_vx_image>(n, 1, VX_TYPE_IMAGE), stream);
     case K_COPY_IMAGE:
@@ -696,8 +787,33 @@ vx_status verify_graph(_vx_graph *g)
         g->order.push_back(g->nodes[pick]);
         for (size_t s : succ[pick]) --indeg[s];
     }
+    // virtual images created with width = height = 0 take their size from the node that writes them
+    for (_vx_node *nd : g->order) {
+        if (nd->kind != K_COLOR_CONVERT && nd->kind != K_COPY_IMAGE) continue;
+        auto *in = param<_vx_image>(nd, 0, VX_TYPE_IMAGE), *out = param<_vx_image>(nd, 1, VX_TYPE_IMAGE);
+        if (in && out && out->is_virtual && out->width == 0 && out->height == 0 && !out->dev) {
+            out->width = in->width;
+            out->height = in->height;
+        }
+    }
     // metadata checks that need no device
     for (_vx_node *nd : g->nodes) {
+        if (nd->kind == K_FIND_HOMOGRAPHY) {
+            auto *a = param<_vx_array>(nd, 0, VX_TYPE_ARRAY), *b = param<_vx_array>(nd, 1, VX_TYPE_ARRAY);
+            auto *m = param<_vx_matrix>(nd, 2, VX_TYPE_MATRIX);
+            auto *k = param<_vx_array>(nd, 9, VX_TYPE_ARRAY);
+            auto *meth = param<_vx_scalar>(nd, 3, VX_TYPE_SCALAR);
+            if (!a || !b || a->item_type != NVX_TYPE_POINT2F || b->item_type != NVX_TYPE_POINT2F || (k && k->item_type != VX_TYPE_UINT8)) {
+                log_msg(ctx, nd, VX_ERROR_INVALID_TYPE, "nvxFindHomographyNode: points must be NVX_TYPE_POINT2F arrays, the mask a VX_TYPE_UINT8 array");
+                return VX_ERROR_INVALID_TYPE;
+            }
+            if (!m || m->data_type != VX_TYPE_FLOAT32 || m->cols != 3 || m->rows != 3) return VX_ERROR_INVALID_DIMENSION;
+            if (!meth || meth->v.e != NVX_FIND_HOMOGRAPHY_METHOD_RANSAC) {
+                log_msg(ctx, nd, VX_ERROR_NOT_SUPPORTED, "nvxFindHomographyNode: only NVX_FIND_HOMOGRAPHY_METHOD_RANSAC is implemented");
+                return VX_ERROR_NOT_SUPPORTED;
+            }
+            if (!(scalar_f32(nd, 4) > 0.0f)) return VX_ERROR_INVALID_VALUE;
+        }
         if (nd->kind == K_PYRLK) {
             auto *a = param<_vx_array>(nd, 2, VX_TYPE_ARRAY), *c = param<_vx_array>(nd, 4, VX_TYPE_ARRAY);
             ItemKind k;
@@ -717,7 +833,13 @@ vx_status verify_graph(_vx_graph *g)
     // bookkeeping for the post-run read-backs
     g->written.clear();
     g->corner_nodes.clear();
+    g->matrices.clear();
     for (_vx_node *nd : g->order) {
+        for (size_t p = 0; p < nd->params.size(); ++p)
+            if (nd->params[p] && nd->spec[p].type == VX_TYPE_MATRIX && nd->spec[p].dir != VX_INPUT) {
+                auto *m = static_cast<_vx_matrix *>(nd->params[p]);
+                if (std::find(g->matrices.begin(), g->matrices.end(), m) == g->matrices.end()) g->matrices.push_back(m);
+            }
         for (size_t p = 0; p < nd->params.size(); ++p)
             if (nd->params[p] && nd->spec[p].type == VX_TYPE_ARRAY && nd->spec[p].dir != VX_INPUT) {
                 auto *a = static_cast<_vx_array *>(nd->params[p]);
@@ -727,7 +849,8 @@ vx_status verify_graph(_vx_graph *g)
             g->corner_nodes.push_back(nd);
     }
     if (!ctx->no_device) {
-        const size_t slots = 2 * (g->written.size() + g->corner_nodes.size() + 1);   // 8 bytes per slot
+        size_t slots = 2 * (g->written.size() + g->corner_nodes.size() + 1);   // 8 bytes per slot
+        for (_vx_matrix *m : g->matrices) slots += 2 * ((m->host.size() + 7) / 8);
         if (slots > g->pinned_slots) {
             if (g->pinned) (void)hipHostFree(g->pinned);
             g->pinned = nullptr;
@@ -767,6 +890,7 @@ vx_status enqueue_graph(_vx_graph *g)
     size_t slot = 0;
     for (_vx_array *a : g->written) { a->count_mirror = &g->pinned[slot]; slot += 2; }
     for (_vx_node *n : g->corner_nodes) { n->num_corners_mirror = reinterpret_cast<uint64_t *>(&g->pinned[slot]); slot += 2; }
+    for (_vx_matrix *m : g->matrices) { m->mirror = reinterpret_cast<float *>(&g->pinned[slot]); slot += 2 * ((m->host.size() + 7) / 8); }
     for (_vx_node *n : g->order) {
         n->timed = ctx->perf || g->perf_enabled || n->perf_enabled;
         if (n->timed) {
@@ -785,6 +909,7 @@ vx_status enqueue_graph(_vx_graph *g)
         }
     }
     for (_vx_array *a : g->written) a->count_mirror = nullptr;
+    for (_vx_matrix *m : g->matrices) m->mirror = nullptr;
     g->scheduled = true;
     g->state = VX_GRAPH_STATE_RUNNING;
     return VX_SUCCESS;
@@ -806,6 +931,10 @@ vx_status finish_graph(_vx_graph *g)
             else if (s->data_type == VX_TYPE_UINT32) s->v.u32 = (vx_uint32)v;
             else if (s->data_type == VX_TYPE_UINT64) s->v.u64 = v;
         }
+    }
+    for (_vx_matrix *m : g->matrices) {
+        memcpy(m->host.data(), &g->pinned[slot], m->host.size());
+        slot += 2 * ((m->host.size() + 7) / 8);
     }
     for (_vx_node *n : g->order)
         if (n->timed) {
@@ -956,7 +1085,7 @@ vx_status vxReleaseContext(vx_context *context)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     // tear down whatever the application left behind: graphs first, then containers, then leaves
     static const vx_enum order[] = { VX_TYPE_GRAPH, VX_TYPE_NODE, VX_TYPE_DELAY, VX_TYPE_PYRAMID, VX_TYPE_IMAGE,
-                                     VX_TYPE_ARRAY, VX_TYPE_SCALAR };
+                                     VX_TYPE_ARRAY, VX_TYPE_MATRIX, VX_TYPE_SCALAR };
     for (vx_enum t : order) {
         for (;;) {
             _vx_reference *victim = nullptr;
@@ -1676,6 +1805,88 @@ vx_node nvxFastTrackNode(vx_graph graph, vx_image input, vx_array output, vx_ima
                        new_scalar(g->ctx, VX_TYPE_UINT32, &threshold), cell_size, num_corners);
 }
 
+vx_node nvxFindHomographyNode(vx_graph graph, vx_array srcPoints, vx_array dstPoints, vx_matrix homography, vx_enum method,
+                              vx_float32 threshold, vx_uint32 maxEstimateIters, vx_uint32 maxRefineIters,
+                              vx_float32 confidence, vx_float32 outlierRatio, vx_array mask)
+{
+    auto *g = as<_vx_graph>(graph, VX_TYPE_GRAPH);
+    if (!g) return nullptr;
+    _vx_scalar *sc[6] = { new_scalar(g->ctx, VX_TYPE_ENUM, &method), new_scalar(g->ctx, VX_TYPE_FLOAT32, &threshold),
+                          new_scalar(g->ctx, VX_TYPE_UINT32, &maxEstimateIters), new_scalar(g->ctx, VX_TYPE_UINT32, &maxRefineIters),
+                          new_scalar(g->ctx, VX_TYPE_FLOAT32, &confidence), new_scalar(g->ctx, VX_TYPE_FLOAT32, &outlierRatio) };
+    vx_node n = make_node(graph, K_FIND_HOMOGRAPHY,
+                          { { VX_INPUT, VX_TYPE_ARRAY, false }, { VX_INPUT, VX_TYPE_ARRAY, false }, { VX_OUTPUT, VX_TYPE_MATRIX, false },
+                            { VX_INPUT, VX_TYPE_SCALAR, false }, { VX_INPUT, VX_TYPE_SCALAR, false }, { VX_INPUT, VX_TYPE_SCALAR, false },
+                            { VX_INPUT, VX_TYPE_SCALAR, false }, { VX_INPUT, VX_TYPE_SCALAR, false }, { VX_INPUT, VX_TYPE_SCALAR, false },
+                            { VX_OUTPUT, VX_TYPE_ARRAY, true } },
+                          { R(srcPoints), R(dstPoints), R(homography), sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], R(mask) });
+    for (auto *x : sc) release_ref(x);   // the node keeps its own references
+    return n;
+}
+
+// ---- matrix --------------------------------------------------------------------------------------
+vx_matrix vxCreateMatrix(vx_context context, vx_enum data_type, vx_size columns, vx_size rows)
+{
+    if (!valid(context) || context->type != VX_TYPE_CONTEXT) return nullptr;
+    if (context->status != VX_SUCCESS) return make_error<vx_matrix>(context, context->status);
+    if (data_type != VX_TYPE_FLOAT32 && data_type != VX_TYPE_INT32 && data_type != VX_TYPE_UINT8)
+        return make_error<vx_matrix>(context, VX_ERROR_INVALID_TYPE, "vxCreateMatrix: unsupported element type");
+    if (columns == 0 || rows == 0) return make_error<vx_matrix>(context, VX_ERROR_INVALID_DIMENSION, "vxCreateMatrix: empty matrix");
+    return new_matrix(context, data_type, columns, rows);
+}
+
+vx_status vxReleaseMatrix(vx_matrix *mat) { return release_handle(mat, VX_TYPE_MATRIX); }
+
+vx_status vxQueryMatrix(vx_matrix mat, vx_enum attribute, void *ptr, vx_size size)
+{
+    auto *m = as<_vx_matrix>(mat, VX_TYPE_MATRIX);
+    if (!m) return VX_ERROR_INVALID_REFERENCE;
+    switch (attribute) {
+    case VX_MATRIX_TYPE: return query_out(ptr, size, &m->data_type, sizeof(vx_enum));
+    case VX_MATRIX_ROWS: { vx_size v = m->rows; return query_out(ptr, size, &v, sizeof(v)); }
+    case VX_MATRIX_COLUMNS: { vx_size v = m->cols; return query_out(ptr, size, &v, sizeof(v)); }
+    case VX_MATRIX_SIZE: { vx_size v = m->host.size(); return query_out(ptr, size, &v, sizeof(v)); }
+    default: return VX_ERROR_NOT_SUPPORTED;
+    }
+}
+
+vx_status vxCopyMatrix(vx_matrix mat, void *user_ptr, vx_enum usage, vx_enum user_mem_type)
+{
+    auto *m = as<_vx_matrix>(mat, VX_TYPE_MATRIX);
+    if (!m) return VX_ERROR_INVALID_REFERENCE;
+    if (!user_ptr || user_mem_type != VX_MEMORY_TYPE_HOST) return VX_ERROR_INVALID_PARAMETERS;
+    if (usage == VX_READ_ONLY) memcpy(user_ptr, m->host.data(), m->host.size());
+    else if (usage == VX_WRITE_ONLY) memcpy(m->host.data(), user_ptr, m->host.size());
+    else return VX_ERROR_INVALID_PARAMETERS;
+    return VX_SUCCESS;
+}
+
+vx_status vxReadMatrix(vx_matrix mat, void *array) { return vxCopyMatrix(mat, array, VX_READ_ONLY, VX_MEMORY_TYPE_HOST); }
+vx_status vxWriteMatrix(vx_matrix mat, const void *array)
+{
+    return vxCopyMatrix(mat, const_cast<void *>(array), VX_WRITE_ONLY, VX_MEMORY_TYPE_HOST);
+}
+
+// ---- virtual objects -----------------------------------------------------------------------------
+vx_array vxCreateVirtualArray(vx_graph graph, vx_enum item_type, vx_size capacity)
+{
+    auto *g = as<_vx_graph>(graph, VX_TYPE_GRAPH);
+    if (!g) return nullptr;
+    return vxCreateArray(g->ctx, item_type, capacity);
+}
+
+vx_image vxCreateVirtualImage(vx_graph graph, vx_uint32 width, vx_uint32 height, vx_df_image color)
+{
+    auto *g = as<_vx_graph>(graph, VX_TYPE_GRAPH);
+    if (!g) return nullptr;
+    if (color != VX_DF_IMAGE_U8 && color != VX_DF_IMAGE_RGBX)
+        return make_error<vx_image>(g->ctx, VX_ERROR_INVALID_FORMAT, "vxCreateVirtualImage: only U8 and RGBX virtual images are supported");
+    if ((width == 0) != (height == 0)) return make_error<vx_image>(g->ctx, VX_ERROR_INVALID_DIMENSION, "vxCreateVirtualImage: both or neither dimension may be 0");
+    _vx_image *im = new_image(g->ctx, width, height, color);
+    im->is_virtual = true;
+    return im;
+}
+
 // ---- immediate mode ----------------------------------------------------------------------------
 static vx_status immediate_begin(vx_context context)
 {
@@ -1690,6 +1901,26 @@ vx_status vxuColorConvert(vx_context context, vx_image input, vx_image output)
     if (s != VX_SUCCESS) return s;
     s = do_color_convert(as<_vx_image>(input, VX_TYPE_IMAGE), as<_vx_image>(output, VX_TYPE_IMAGE), context->stream);
     return s == VX_SUCCESS ? hip_status(hipStreamSynchronize(context->stream)) : s;
+}
+
+vx_status nvxuFindHomography(vx_context context, vx_array srcPoints, vx_array dstPoints, vx_matrix homography, vx_enum method,
+                             vx_float32 threshold, vx_uint32 maxEstimateIters, vx_uint32 maxRefineIters, vx_float32 confidence,
+                             vx_float32 outlierRatio, vx_array mask)
+{
+    vx_status s = immediate_begin(context);
+    if (s != VX_SUCCESS) return s;
+    auto *m = as<_vx_matrix>(homography, VX_TYPE_MATRIX);
+    auto *k = mask ? as<_vx_array>(mask, VX_TYPE_ARRAY) : nullptr;
+    if (!m || (mask && !k)) return VX_ERROR_INVALID_REFERENCE;
+    s = immediate_scratch(context, homography_scratch_bytes(homography_hypotheses(confidence, outlierRatio, maxEstimateIters)));
+    if (s != VX_SUCCESS) return s;
+    s = do_find_homography(as<_vx_array>(srcPoints, VX_TYPE_ARRAY), as<_vx_array>(dstPoints, VX_TYPE_ARRAY), m, method, threshold,
+                           maxEstimateIters, maxRefineIters, confidence, outlierRatio, k, context->scratch, context->scratch_size,
+                           context->stream);
+    if (s != VX_SUCCESS) return s;
+    if (hipMemcpyAsync(m->host.data(), m->dev, m->host.size(), hipMemcpyDeviceToHost, context->stream) != hipSuccess) return VX_FAILURE;
+    if (k) return refresh_count_now(k, context->stream);
+    return hip_status(hipStreamSynchronize(context->stream));
 }
 
 vx_status nvxuCopyImage(vx_context context, vx_image src, vx_image dst)

@@ -97,6 +97,9 @@ def lib():
             raise RuntimeError(
                 "libvisualslam_amd.so is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`); there is no CPU fallback")
+        # PyTorch bundles its own copy of the HIP runtime: load it first, so that this process has ONE runtime
+        # (the library then binds to the copy already loaded; two copies each see "no device" from the other's side)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         P = C.c_void_p
         u32, f32 = C.c_uint32, C.c_float

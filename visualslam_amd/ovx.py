@@ -20,6 +20,7 @@ NVX_ERROR_NO_GPU = -1000
 
 VX_TYPE_UINT32, VX_TYPE_FLOAT32, VX_TYPE_SIZE, VX_TYPE_BOOL, VX_TYPE_ENUM = 0x007, 0x00A, 0x00D, 0x010, 0x00C
 VX_TYPE_KEYPOINT = 0x021
+VX_TYPE_UINT8, VX_TYPE_MATRIX = 0x003, 0x80B
 VX_TYPE_IMAGE, VX_TYPE_ARRAY, VX_TYPE_PYRAMID, VX_TYPE_ERROR = 0x80F, 0x80E, 0x809, 0x811
 NVX_TYPE_POINT2F, NVX_TYPE_KEYPOINTF = 0x400, 0x403
 VX_DF_IMAGE_U8, VX_DF_IMAGE_RGBX = nvxcu.NVXCU_DF_IMAGE_U8, nvxcu.NVXCU_DF_IMAGE_RGBX
@@ -37,7 +38,9 @@ VX_MEMORY_TYPE_HOST, NVX_MEMORY_TYPE_HIP = 0x0E001, 0x0E100
 VX_TERM_CRITERIA_ITERATIONS, VX_TERM_CRITERIA_EPSILON, VX_TERM_CRITERIA_BOTH = 0x17000, 0x17001, 0x17002
 NVX_GRAPH_VERIFY_OPTIONS = 0x80280
 VX_SCALE_PYRAMID_HALF = 0.5
-K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE = range(6)
+K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE, K_FIND_HOMOGRAPHY = range(7)
+VX_MATRIX_TYPE, VX_MATRIX_ROWS, VX_MATRIX_COLUMNS, VX_MATRIX_SIZE = 0x80B00, 0x80B01, 0x80B02, 0x80B03
+NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, NVX_FIND_HOMOGRAPHY_METHOD_LMEDS = 0x80300, 0x80301
 
 
 class vx_perf_t(C.Structure):
@@ -122,6 +125,16 @@ _SIGS = {
     "nvxuHarrisTrack": (C.c_int32, [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_uint32, C.c_void_p]),
     "nvxuFastTrack": (C.c_int32, [C.c_void_p] * 5 + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "nvxuCopyImage": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vxCreateMatrix": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_size_t, C.c_size_t]),
+    "vxReleaseMatrix": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxQueryMatrix": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxCopyMatrix": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "vxReadMatrix": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "vxWriteMatrix": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "vxCreateVirtualArray": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_size_t]),
+    "vxCreateVirtualImage": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "nvxFindHomographyNode": (C.c_void_p, [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
+    "nvxuFindHomography": (C.c_int32, [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
     "visualslam_amd_graph_order": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
 }
 
