@@ -275,3 +275,121 @@ def test_context_release_reclaims_everything(monkeypatch):
     h = C.c_void_p(c)
     assert L.vxReleaseContext(C.byref(h)) == ovx.VX_SUCCESS          # nothing released by hand: no crash, no leak report
     assert L.vxGetStatus(ft["g"]) == ovx.VX_ERROR_INVALID_REFERENCE  # handles are dead afterwards
+
+
+def test_matrix_object(ctx):
+    """vx_matrix as demos/video_stabilizer/stabilizer.cpp:170-176 uses it: 3x3 FLOAT32, written and read whole"""
+    import numpy as np
+    m = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    assert L.vxGetStatus(m) == ovx.VX_SUCCESS
+    assert ovx.query("vxQueryReference", m, ovx.VX_REFERENCE_TYPE, C.c_int32) == ovx.VX_TYPE_MATRIX
+    assert ovx.query("vxQueryMatrix", m, ovx.VX_MATRIX_TYPE, C.c_int32) == ovx.VX_TYPE_FLOAT32
+    assert ovx.query("vxQueryMatrix", m, ovx.VX_MATRIX_ROWS, C.c_size_t) == 3
+    assert ovx.query("vxQueryMatrix", m, ovx.VX_MATRIX_COLUMNS, C.c_size_t) == 3
+    assert ovx.query("vxQueryMatrix", m, ovx.VX_MATRIX_SIZE, C.c_size_t) == 36
+    eye = np.eye(3, dtype=np.float32) * 2 + np.arange(9, dtype=np.float32).reshape(3, 3)
+    assert L.vxCopyMatrix(m, eye.ctypes.data, ovx.VX_WRITE_ONLY, ovx.VX_MEMORY_TYPE_HOST) == ovx.VX_SUCCESS
+    back = np.zeros((3, 3), np.float32)
+    assert L.vxCopyMatrix(m, back.ctypes.data, ovx.VX_READ_ONLY, ovx.VX_MEMORY_TYPE_HOST) == ovx.VX_SUCCESS
+    assert (back == eye).all()
+    back[:] = 0
+    assert L.vxReadMatrix(m, back.ctypes.data) == ovx.VX_SUCCESS and (back == eye).all()      # OpenVX 1.0 spellings
+    assert L.vxWriteMatrix(m, np.zeros(9, np.float32).ctypes.data) == ovx.VX_SUCCESS
+    assert L.vxReadMatrix(m, back.ctypes.data) == ovx.VX_SUCCESS and (back == 0).all()
+    assert L.vxCopyMatrix(m, None, ovx.VX_READ_ONLY, ovx.VX_MEMORY_TYPE_HOST) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxCopyMatrix(m, back.ctypes.data, 0x7777, ovx.VX_MEMORY_TYPE_HOST) == ovx.VX_ERROR_INVALID_PARAMETERS
+    img = L.vxCreateImage(ctx, 8, 8, ovx.VX_DF_IMAGE_U8)
+    assert L.vxQueryMatrix(img, ovx.VX_MATRIX_ROWS, C.byref(C.c_size_t()), 8) == ovx.VX_ERROR_INVALID_REFERENCE
+    for bad in (L.vxCreateMatrix(ctx, ovx.VX_TYPE_BOOL, 3, 3), L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 0, 3),
+                L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 0)):
+        assert bad is not None and L.vxGetStatus(bad) != ovx.VX_SUCCESS
+    h = C.c_void_p(m)
+    assert L.vxReleaseMatrix(C.byref(h)) == ovx.VX_SUCCESS and h.value is None
+    assert L.vxReleaseMatrix(C.byref(h)) == ovx.VX_SUCCESS
+    assert L.vxReleaseMatrix(C.byref(C.c_void_p(img))) == ovx.VX_ERROR_INVALID_REFERENCE
+
+
+def test_virtual_objects(ctx):
+    """virtual images/arrays (stabilizer.cpp:230-262): created against a graph; a 0x0 virtual image takes its
+    size from the node that writes it when the graph is verified"""
+    g = L.vxCreateGraph(ctx)
+    frame = L.vxCreateImage(ctx, 96, 64, ovx.VX_DF_IMAGE_RGBX)
+    gray = L.vxCreateVirtualImage(g, 0, 0, ovx.VX_DF_IMAGE_U8)
+    assert L.vxGetStatus(gray) == ovx.VX_SUCCESS
+    pyr = L.vxCreatePyramid(ctx, 3, 0.5, 96, 64, ovx.VX_DF_IMAGE_U8)
+    copy = L.vxCreateImage(ctx, 96, 64, ovx.VX_DF_IMAGE_U8)
+    assert L.vxGetStatus(L.vxColorConvertNode(g, frame, gray)) == ovx.VX_SUCCESS
+    assert L.vxGetStatus(L.nvxCopyImageNode(g, gray, copy)) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    assert ovx.query("vxQueryImage", gray, ovx.VX_IMAGE_WIDTH, C.c_uint32) == 96
+    assert ovx.query("vxQueryImage", gray, ovx.VX_IMAGE_HEIGHT, C.c_uint32) == 64
+    assert _order(g) == [ovx.K_COLOR_CONVERT, ovx.K_COPY_IMAGE]
+    sized = L.vxCreateVirtualImage(g, 32, 16, ovx.VX_DF_IMAGE_U8)
+    assert ovx.query("vxQueryImage", sized, ovx.VX_IMAGE_WIDTH, C.c_uint32) == 32
+    assert L.vxGetStatus(L.vxCreateVirtualImage(g, 32, 0, ovx.VX_DF_IMAGE_U8)) == ovx.VX_ERROR_INVALID_DIMENSION
+    assert L.vxGetStatus(L.vxCreateVirtualImage(g, 32, 32, 0x12345678)) == ovx.VX_ERROR_INVALID_FORMAT
+    assert L.vxCreateVirtualImage(ctx, 32, 32, ovx.VX_DF_IMAGE_U8) is None          # a context is not a graph
+    arr = L.vxCreateVirtualArray(g, ovx.VX_TYPE_UINT8, 100)
+    assert L.vxGetStatus(arr) == ovx.VX_SUCCESS
+    assert ovx.query("vxQueryArray", arr, ovx.VX_ARRAY_CAPACITY, C.c_size_t) == 100
+    assert ovx.query("vxQueryArray", arr, ovx.VX_ARRAY_ITEMSIZE, C.c_size_t) == 1
+    assert L.vxCreateVirtualArray(ctx, ovx.VX_TYPE_UINT8, 100) is None
+    ovx.release("Pyramid", pyr)
+
+
+def _homography_graph(ctx, method=None, pts_type=None, mask_type=None, mshape=(3, 3), mtype=None, thr=3.0):
+    g = L.vxCreateGraph(ctx)
+    pts_type = ovx.NVX_TYPE_POINT2F if pts_type is None else pts_type
+    a = L.vxCreateArray(ctx, pts_type, 64)
+    b = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 64)
+    m = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32 if mtype is None else mtype, *mshape)
+    k = L.vxCreateVirtualArray(g, ovx.VX_TYPE_UINT8 if mask_type is None else mask_type, 64)
+    n = L.nvxFindHomographyNode(g, a, b, m, ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC if method is None else method,
+                                thr, 2000, 10, 0.995, 0.45, k)
+    return g, n
+
+
+def test_find_homography_node_verification(ctx):
+    """nvxFindHomographyNode with the video stabilizer's arguments (stabilizer.cpp:264-273): metadata is checked
+    when the graph is verified, nothing runs without a device"""
+    g, n = _homography_graph(ctx)
+    assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    assert _order(g) == [ovx.K_FIND_HOMOGRAPHY]
+    assert L.vxProcessGraph(g) == ovx.NVX_ERROR_NO_GPU
+    g, _ = _homography_graph(ctx, method=ovx.NVX_FIND_HOMOGRAPHY_METHOD_LMEDS)
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_NOT_SUPPORTED
+    g, _ = _homography_graph(ctx, pts_type=ovx.NVX_TYPE_KEYPOINTF)
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_TYPE
+    g, _ = _homography_graph(ctx, mask_type=ovx.NVX_TYPE_POINT2F)
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_TYPE
+    g, _ = _homography_graph(ctx, mshape=(3, 2))
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_DIMENSION
+    g, _ = _homography_graph(ctx, mtype=ovx.VX_TYPE_UINT8)
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_DIMENSION
+    g, _ = _homography_graph(ctx, thr=0.0)
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_VALUE
+    # required parameters
+    g = L.vxCreateGraph(ctx)
+    a = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 8)
+    m = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    n = L.nvxFindHomographyNode(g, a, None, m, ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, None)
+    assert L.vxGetStatus(n) == ovx.VX_ERROR_INVALID_PARAMETERS
+    n = L.nvxFindHomographyNode(g, a, a, a, ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, None)
+    assert L.vxGetStatus(n) == ovx.VX_ERROR_INVALID_REFERENCE
+    # the immediate form cannot run either
+    assert L.nvxuFindHomography(ctx, a, a, m, ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, None) \
+        == ovx.NVX_ERROR_NO_GPU
+
+
+def test_tracker_graph_feeding_homography_orders_after_lk(ctx):
+    """BASELINE config C5: the PyrLK matches feed nvxFindHomographyNode in the same graph"""
+    ft = _ft_graph(ctx, order="mixed")
+    m = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    n = L.nvxFindHomographyNode(ft["g"], L.vxGetReferenceFromDelay(ft["pts_delay"], -1), ft["kp_curr"], m,
+                                ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, None)
+    assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(ft["g"]) == ovx.VX_SUCCESS
+    order = _order(ft["g"])
+    assert order.index(ovx.K_FIND_HOMOGRAPHY) > order.index(ovx.K_PYRLK)
+    assert order[:3] == [ovx.K_COLOR_CONVERT, ovx.K_GAUSSIAN_PYRAMID, ovx.K_PYRLK]
