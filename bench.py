@@ -82,6 +82,9 @@ def main():
                     help="ovx: OpenVX graph API (default, the north-star path); thin: nvxcu primitives")
     ap.add_argument("--host-threads", type=int, default=1,
                     help="ovx: 1 = one host thread per camera stream calling vxProcessGraph (default); 0 = one thread scheduling all graphs")
+    ap.add_argument("--homography", action="store_true",
+                    help="BASELINE configs[4]: append nvxFindHomographyNode (batched RANSAC on the PyrLK matches, the video "
+                         "stabilizer's arguments) to every stream's graph; a separate workload, never the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,6 +120,8 @@ def main():
     host_frames = [synth.to_rgbx(synth.gray_frame(base, t, 1234)) for t in range(args.ring)]
     phases = [(s * 3) % args.ring for s in my_streams]     # streams look at different frames
 
+    if args.homography and args.api != "ovx":
+        raise SystemExit("--homography needs --api ovx (nvxFindHomographyNode is a graph node)")
     if args.api == "ovx":
         # the north-star path: one OpenVX graph per camera stream (ColorConvert -> GaussianPyramid ->
         # OpticalFlowPyrLK -> HarrisTrack), per frame vxSetParameterByIndex x2 + vxAgeDelay x2 +
@@ -132,7 +137,9 @@ def main():
             img = L.vxCreateImage(ctx, WIDTH, HEIGHT, ovx.VX_DF_IMAGE_RGBX)
             ovx.write_image(img, f)
             ring.append(img)
-        trackers = [VxFeatureTracker(ctx, params, WIDTH, HEIGHT, ring[ph], None) for ph in phases]
+        trackers = [VxFeatureTracker(ctx, params, WIDTH, HEIGHT, ring[ph], None, homography=args.homography) for ph in phases]
+        if args.homography:
+            ovx.check(L.vxDirective(trackers[0].hg, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
         # HIP events around the PyrLK node of stream 0 only (two event records per frame on that graph's stream)
         ovx.check(L.vxDirective(trackers[0].lk, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
 
@@ -226,7 +233,8 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
+            "config": {"workload": WORKLOAD + (" + nvxFindHomographyNode (RANSAC 3.0 px, 56 hypotheses, <=10 refits) on the matches"
+                                               if args.homography else ""), "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
                        "frame_ring": args.ring, "api": api_desc},
             "tracks_per_sec": fps * float(np.mean(n_tracks)),
             "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),
@@ -236,7 +244,12 @@ def main():
                          "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "launch_ms": lk_ms, "algorithmic_bytes_per_launch": BYTES_LK},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if args.homography:
+            perf = ovx.query("vxQueryNode", trackers[0].hg, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
+            H, mask = trackers[0].homography()
+            out["homography"] = {"node_ms": perf.avg * 1e-6, "inliers_stream0": int((mask != 0).sum()), "points_stream0": int(len(mask)),
+                                 "matrix_stream0": [float(x) for x in H.T.reshape(-1)]}
+        if not args.no_cpu_baseline and world == 1 and not args.homography:
             out["cpu_baseline"] = cpu_baseline(host_frames, params)
         print(json.dumps(out), flush=True)
     barrier(world)

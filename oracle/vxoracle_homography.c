@@ -15,8 +15,9 @@
  *     hypotheses are independent and evaluated as one batch;
  *   * hypothesis k draws 4 distinct usable correspondences with the LCG below (seeded by k), and maps them
  *     exactly (Heckbert's square-to-quadrilateral construction, binary64);
- *   * inliers: reprojection error^2 <= threshold^2, evaluated in binary32 with the hypothesis rounded to
- *     binary32 (h22 = 1); best = most inliers, ties to the lowest k;
+ *   * inliers: reprojection error <= threshold, evaluated in binary32 with the hypothesis rounded to binary32
+ *     (h22 = 1) and without a division: with (X, Y, W) = H (x, y, 1), the point is an inlier when W > 1e-6 and
+ *     (X - uW)^2 + (Y - vW)^2 <= threshold^2 W^2;  best = most inliers, ties to the lowest k;
  *   * refinement, at most `max_refine_iters` times: least-squares homography (h22 = 1, normal equations in
  *     binary64 on coordinates normalised once over all usable points) over the current inliers; accepted
  *     while the inlier count does not drop; stops when the inlier set stops changing;
@@ -124,9 +125,8 @@ static inline int hg_inlier(const float *H, float x, float y, float u, float v, 
     const float X = fmaf(H[0], x, fmaf(H[1], y, H[2]));
     const float Y = fmaf(H[3], x, fmaf(H[4], y, H[5]));
     const float W = fmaf(H[6], x, fmaf(H[7], y, H[8]));
-    if (!(W > 1e-6f)) return 0;
-    const float du = X / W - u, dv = Y / W - v;
-    return fmaf(du, du, dv * dv) <= thr2;
+    const float ex = fmaf(-u, W, X), ey = fmaf(-v, W, Y);
+    return (W > 1e-6f) & (fmaf(ex, ex, ey * ey) <= thr2 * (W * W));
 }
 
 static double hg_tree(double *p)

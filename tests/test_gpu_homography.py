@@ -49,7 +49,11 @@ def _read_matrix(m):
 
 @pytest.mark.parametrize("n,thr,seed,noise,outl", [(4096, 3.0, 0, 0.3, 0.3), (1000, 0.5, 1, 0.1, 0.45), (1000, 3.0, 2, 1.0, 0.6),
                                                     (37, 3.0, 3, 0.2, 0.2), (9000, 2.0, 4, 0.5, 0.35)])
-def test_immediate_matches_oracle(ctx, n, thr, seed, noise, outl):
+@pytest.mark.parametrize("large_array_kernels", [False, True])
+def test_immediate_matches_oracle(ctx, monkeypatch, n, thr, seed, noise, outl, large_array_kernels):
+    # arrays of capacity <= 4096 take the register-resident kernels; the switch forces the kernels for larger arrays
+    if large_array_kernels:
+        monkeypatch.setenv("VISUALSLAM_AMD_HG_GENERIC", "1")
     src, dst, _ = scene(n=n, noise=noise, outliers=outl, seed=seed)
     a, b = _arrays(ctx, src, dst)
     m = _matrix(ctx)
@@ -65,7 +69,10 @@ def test_immediate_matches_oracle(ctx, n, thr, seed, noise, outl):
     assert cw > 4
 
 
-def test_refine_and_estimate_limits(ctx):
+@pytest.mark.parametrize("large_array_kernels", [False, True])
+def test_refine_and_estimate_limits(ctx, monkeypatch, large_array_kernels):
+    if large_array_kernels:
+        monkeypatch.setenv("VISUALSLAM_AMD_HG_GENERIC", "1")
     src, dst, _ = scene(n=1500, noise=0.8, seed=7)
     a, b = _arrays(ctx, src, dst)
     for est, ref in ((2000, 0), (5, 10), (1, 1), (2000, 3)):

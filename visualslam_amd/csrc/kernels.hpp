@@ -111,7 +111,9 @@ struct HomographyParams {
     uint32_t *mask_count;                 // item count of the mask array (device), may be null iff mask is
     uint32_t *mask_count_host = nullptr;
     uint32_t mask_capacity;
-    void *scratch;                        // homography_scratch_bytes(hypotheses) bytes, 8-byte aligned
+    void *scratch;                        // homography_scratch_bytes(hypotheses) bytes, 16-byte aligned; its first 16 bytes
+                                          // (the ticket word) must be zero before the launch -- the kernel leaves them zero,
+                                          // so a buffer used by nothing else needs clearing once
 };
 uint32_t homography_hypotheses(float confidence, float outlier_ratio, uint32_t max_estimate_iters);
 size_t homography_scratch_bytes(uint32_t hypotheses);

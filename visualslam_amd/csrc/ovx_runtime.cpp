@@ -659,6 +659,8 @@ vx_status homography_node_scratch(_vx_node *n)
         n->scratch_size = 0;
         if (hipMalloc(&n->scratch, need) != hipSuccess) return VX_ERROR_NO_MEMORY;
         n->scratch_size = need;
+        // the ticket word; this buffer is the node's alone and the kernel leaves the word zero
+        if (hipMemset(n->scratch, 0, 16) != hipSuccess) return VX_FAILURE;
     }
     return VX_SUCCESS;
 }
@@ -1914,6 +1916,8 @@ vx_status nvxuFindHomography(vx_context context, vx_array srcPoints, vx_array ds
     if (!m || (mask && !k)) return VX_ERROR_INVALID_REFERENCE;
     s = immediate_scratch(context, homography_scratch_bytes(homography_hypotheses(confidence, outlierRatio, maxEstimateIters)));
     if (s != VX_SUCCESS) return s;
+    // the context's scratch buffer is shared with the other immediate-mode calls: clear the ticket word every time
+    if (hipMemsetAsync(context->scratch, 0, 16, context->stream) != hipSuccess) return VX_FAILURE;
     s = do_find_homography(as<_vx_array>(srcPoints, VX_TYPE_ARRAY), as<_vx_array>(dstPoints, VX_TYPE_ARRAY), m, method, threshold,
                            maxEstimateIters, maxRefineIters, confidence, outlierRatio, k, context->scratch, context->scratch_size,
                            context->stream);

@@ -9,7 +9,9 @@ L = ovx.lib()
 class VxFeatureTracker:
     """call-for-call transcription of FeatureTrackerImpl (feature_tracker.cpp:127-449)"""
 
-    def __init__(self, ctx, p, w, h, first_frame, mask):
+    def __init__(self, ctx, p, w, h, first_frame, mask, homography=False):
+        """homography=True appends the video stabilizer's / SFM sample's next stage to the same graph
+        (demos/video_stabilizer/stabilizer.cpp:264-273): nvxFindHomographyNode on the PyrLK matches"""
         self.ctx, self.p = ctx, p
         pex = L.vxCreatePyramid(ctx, p.pyr_levels, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
         self.pyr_delay = L.vxCreateDelay(ctx, pex, 2)
@@ -33,6 +35,13 @@ class VxFeatureTracker:
             self.det = L.nvxHarrisTrackNode(self.g, gray, out, mask, self.kp_curr, p.harris_k, p.harris_thresh, p.detector_cell_size, None)
         else:
             self.det = L.nvxFastTrackNode(self.g, gray, out, mask, self.kp_curr, p.fast_type, p.fast_thresh, p.detector_cell_size, None)
+        self.hg = self.hg_matrix = self.hg_mask = None
+        if homography:
+            self.hg_matrix = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+            self.hg_mask = L.vxCreateArray(ctx, ovx.VX_TYPE_UINT8, p.array_capacity)
+            self.hg = L.nvxFindHomographyNode(self.g, L.vxGetReferenceFromDelay(self.pts_delay, -1), self.kp_curr, self.hg_matrix,
+                                              ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, self.hg_mask)
+            assert L.vxGetStatus(self.hg) == ovx.VX_SUCCESS
         for n in (self.cvt, self.pyr, self.lk, self.det):
             assert L.vxGetStatus(n) == ovx.VX_SUCCESS
         opt = b"-O3"
@@ -72,6 +81,13 @@ class VxFeatureTracker:
 
     def merged(self):
         return ovx.read_array(L.vxGetReferenceFromDelay(self.pts_delay, 0))
+
+    def homography(self):
+        """(H as the matrix object stores it: element [c][r] = H[r][c], inlier mask)"""
+        import numpy as np
+        m = np.zeros((3, 3), np.float32)
+        ovx.check(L.vxCopyMatrix(self.hg_matrix, m.ctypes.data, ovx.VX_READ_ONLY, ovx.VX_MEMORY_TYPE_HOST))
+        return m, ovx.read_array(self.hg_mask)
 
     def wait(self):
         ovx.check(L.vxWaitGraph(self.g), "vxWaitGraph")
