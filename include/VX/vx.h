@@ -66,6 +66,8 @@ typedef struct _vx_pyramid   *vx_pyramid;
 typedef struct _vx_array     *vx_array;
 typedef struct _vx_delay     *vx_delay;
 typedef struct _vx_scalar    *vx_scalar;
+typedef struct _vx_kernel    *vx_kernel;
+typedef struct _vx_meta_format *vx_meta_format;
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum vx_status_e {
@@ -200,6 +202,11 @@ enum vx_border_e {
     VX_BORDER_MODE_UNDEFINED = VX_BORDER_UNDEFINED, VX_BORDER_MODE_CONSTANT = VX_BORDER_CONSTANT,
     VX_BORDER_MODE_REPLICATE = VX_BORDER_REPLICATE
 };
+enum vx_interpolation_type_e {      /* demos/video_stabilizer/stabilizer.cpp:295 */
+    VX_INTERPOLATION_NEAREST_NEIGHBOR = 0x04000 + 0x10000, VX_INTERPOLATION_BILINEAR, VX_INTERPOLATION_AREA,
+    VX_INTERPOLATION_TYPE_NEAREST_NEIGHBOR = VX_INTERPOLATION_NEAREST_NEIGHBOR,
+    VX_INTERPOLATION_TYPE_BILINEAR = VX_INTERPOLATION_BILINEAR, VX_INTERPOLATION_TYPE_AREA = VX_INTERPOLATION_AREA
+};
 enum vx_color_space_e { VX_COLOR_SPACE_NONE = 0x09000, VX_COLOR_SPACE_BT601_525, VX_COLOR_SPACE_BT601_625,
                         VX_COLOR_SPACE_BT709, VX_COLOR_SPACE_DEFAULT = VX_COLOR_SPACE_BT709 };
 enum vx_channel_range_e { VX_CHANNEL_RANGE_FULL = 0x0A000, VX_CHANNEL_RANGE_RESTRICTED };
@@ -237,6 +244,18 @@ typedef struct _vx_border_t {
     vx_enum mode;
     union { vx_uint8 U8; vx_int16 S16; vx_uint16 U16; vx_int32 S32; vx_uint32 U32; vx_uint8 RGB[3]; vx_uint8 RGBX[4]; } constant_value;
 } vx_border_t;
+
+typedef union _vx_pixel_value_t {    /* demos/video_stabilizer/stabilizer.cpp:399-404 */
+    vx_uint8 RGB[3];
+    vx_uint8 RGBX[4];
+    vx_uint8 YUV[3];
+    vx_uint8 U8;
+    vx_uint16 U16;
+    vx_int16 S16;
+    vx_uint32 U32;
+    vx_int32 S32;
+    vx_uint8 reserved[16];
+} vx_pixel_value_t;
 
 typedef void (VX_CALLBACK *vx_log_callback_f)(vx_context context, vx_reference ref, vx_status status,
                                              const vx_char string[]);
@@ -279,6 +298,16 @@ VX_API_ENTRY vx_status VX_API_CALL vxUnmapImagePatch(vx_image image, vx_map_id m
 VX_API_ENTRY vx_status VX_API_CALL vxCopyImagePatch(vx_image image, const vx_rectangle_t *rect, vx_uint32 plane_index,
                                                     const vx_imagepatch_addressing_t *user_addr, void *user_ptr,
                                                     vx_enum usage, vx_enum user_mem_type);
+
+/* stabilizer.cpp:404: an image every pixel of which holds `value` (U8 and RGBX); ordinary memory here, so it may also
+ * be written */
+VX_API_ENTRY vx_image VX_API_CALL vxCreateUniformImage(vx_context context, vx_uint32 width, vx_uint32 height, vx_df_image color,
+                                                       const vx_pixel_value_t *value);
+/* demos/video_stabilizer/main_video_stabilizer.cpp:233-235: a view of `rect` sharing the parent's memory (the parent
+ * stays alive while the view does) */
+VX_API_ENTRY vx_image VX_API_CALL vxCreateImageFromROI(vx_image img, const vx_rectangle_t *rect);
+/* main_video_stabilizer.cpp:225: the whole image (every kernel here defines all of its output pixels) */
+VX_API_ENTRY vx_status VX_API_CALL vxGetValidRegionImage(vx_image image, vx_rectangle_t *rect);
 
 /* ---- pyramid ------------------------------------------------------------------------------ */
 /* feature_tracker.cpp:287 (level i is ceil(base * scale^i), feature_tracker_nvxcu.cpp:164-176) */
@@ -379,6 +408,49 @@ VX_API_ENTRY vx_node VX_API_CALL vxOpticalFlowPyrLKNode(vx_graph graph, vx_pyram
                                                         vx_array new_points, vx_enum termination, vx_scalar epsilon,
                                                         vx_scalar num_iterations, vx_scalar use_initial_estimate,
                                                         vx_size window_dimension);
+
+/* demos/video_stabilizer/stabilizer.cpp:292-295.  output(x,y) = input(x0/z0, y0/z0) with
+ *   x0 = m[0][0] x + m[1][0] y + m[2][0],  y0 = m[0][1] x + m[1][1] y + m[2][1],  z0 = m[0][2] x + m[1][2] y + m[2][2]
+ * for the 3x3 FLOAT32 matrix as stored (OpenVX: the matrix is kept column by column -- the layout
+ * demos/video_stabilizer/truncate_transform_node.cpp:163-165 writes).  U8 and RGBX; NEAREST_NEIGHBOR and BILINEAR;
+ * samples outside the input read the node's constant border value (VX_BORDER_UNDEFINED = constant 0). */
+VX_API_ENTRY vx_node VX_API_CALL vxWarpPerspectiveNode(vx_graph graph, vx_image input, vx_matrix matrix, vx_enum type, vx_image output);
+
+/* ---- user kernels (demos/video_stabilizer/{homography_filter,smoother,truncate_transform}_node.cpp) ------------- */
+/* Host callbacks executed inside the graph: the runtime drains the graph's HIP stream before calling `func`, so every
+ * object the earlier nodes wrote is readable through the ordinary accessors, and what `func` writes is seen by the
+ * nodes after it. */
+typedef vx_status (VX_CALLBACK *vx_kernel_f)(vx_node node, const vx_reference *parameters, vx_uint32 num);
+typedef vx_status (VX_CALLBACK *vx_kernel_initialize_f)(vx_node node, const vx_reference *parameters, vx_uint32 num);
+typedef vx_status (VX_CALLBACK *vx_kernel_deinitialize_f)(vx_node node, const vx_reference *parameters, vx_uint32 num);
+typedef vx_status (VX_CALLBACK *vx_kernel_validate_f)(vx_node node, const vx_reference parameters[], vx_uint32 num,
+                                                      vx_meta_format metas[]);
+enum vx_kernel_attribute_e {
+    VX_KERNEL_PARAMETERS = 0x80400, VX_KERNEL_NAME, VX_KERNEL_ENUM, VX_KERNEL_LOCAL_DATA_SIZE,
+    VX_KERNEL_ATTRIBUTE_PARAMETERS = VX_KERNEL_PARAMETERS, VX_KERNEL_ATTRIBUTE_NAME = VX_KERNEL_NAME,
+    VX_KERNEL_ATTRIBUTE_ENUM = VX_KERNEL_ENUM
+};
+#define VX_KERNEL_BASE(vendor, lib) (((vendor) << 20) | ((lib) << 12))
+/* homography_filter_node.cpp:210 */
+VX_API_ENTRY vx_status VX_API_CALL vxAllocateUserKernelId(vx_context context, vx_enum *pKernelEnumId);
+/* homography_filter_node.cpp:218-225 */
+VX_API_ENTRY vx_kernel VX_API_CALL vxAddUserKernel(vx_context context, const vx_char name[VX_MAX_KERNEL_NAME], vx_enum enumeration,
+                                                   vx_kernel_f func_ptr, vx_uint32 numParams, vx_kernel_validate_f validate,
+                                                   vx_kernel_initialize_f init, vx_kernel_deinitialize_f deinit);
+/* homography_filter_node.cpp:234-237 */
+VX_API_ENTRY vx_status VX_API_CALL vxAddParameterToKernel(vx_kernel kernel, vx_uint32 index, vx_enum dir, vx_enum data_type, vx_enum state);
+VX_API_ENTRY vx_status VX_API_CALL vxFinalizeKernel(vx_kernel kernel);
+VX_API_ENTRY vx_status VX_API_CALL vxRemoveKernel(vx_kernel kernel);
+VX_API_ENTRY vx_status VX_API_CALL vxReleaseKernel(vx_kernel *kernel);
+VX_API_ENTRY vx_status VX_API_CALL vxQueryKernel(vx_kernel kernel, vx_enum attribute, void *ptr, vx_size size);
+/* homography_filter_node.cpp:263 -- finalized kernels only */
+VX_API_ENTRY vx_kernel VX_API_CALL vxGetKernelByName(vx_context context, const vx_char *name);
+VX_API_ENTRY vx_kernel VX_API_CALL vxGetKernelByEnum(vx_context context, vx_enum kernel);
+/* homography_filter_node.cpp:267: a node with every parameter unset; vxSetParameterByIndex fills them in */
+VX_API_ENTRY vx_node VX_API_CALL vxCreateGenericNode(vx_graph graph, vx_kernel kernel);
+/* homography_filter_node.cpp:197-199: the validator describes each output; vxVerifyGraph compares it with the object bound */
+VX_API_ENTRY vx_status VX_API_CALL vxSetMetaFormatAttribute(vx_meta_format meta, vx_enum attribute, const void *ptr, vx_size size);
+VX_API_ENTRY vx_status VX_API_CALL vxSetMetaFormatFromReference(vx_meta_format meta, vx_reference exemplar);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,9 @@ VX_API_ENTRY vx_status VX_API_CALL vxuOpticalFlowPyrLK(vx_context context, vx_py
                                                        vx_scalar num_iterations, vx_scalar use_initial_estimate,
                                                        vx_size window_dimension);
 
+/* immediate form of vxWarpPerspectiveNode (VX/vx.h); border = constant 0 */
+VX_API_ENTRY vx_status VX_API_CALL vxuWarpPerspective(vx_context context, vx_image input, vx_matrix matrix, vx_enum type, vx_image output);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,3 +207,21 @@ def find_homography(src, dst, threshold=3.0, max_estimate_iters=2000, max_refine
     cnt = f(src.ctypes.data, dst.ctypes.data, n, threshold, max_estimate_iters, max_refine_iters, confidence,
             outlier_ratio, H.ctypes.data, mask.ctypes.data)
     return H.reshape(3, 3), mask[:n], int(cnt)
+
+
+def warp_perspective(img, matrix_data, out_shape=None, bilinear=True, border=None):
+    """vxWarpPerspectiveNode as the oracle defines it.  img: (h,w) uint8 or (h,w,4) uint8; matrix_data: the 3x3
+    float32 vx_matrix contents as the API stores them (element [c][r] = M[r][c]); returns the warped image."""
+    img = np.ascontiguousarray(img, np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    oh, ow = out_shape if out_shape is not None else (h, w)
+    out = np.zeros((oh, ow) + (() if ch == 1 else (ch,)), np.uint8)
+    m = np.ascontiguousarray(np.asarray(matrix_data, np.float32).reshape(3, 3).T)     # row-major M
+    b = np.zeros(4, np.uint8) if border is None else np.ascontiguousarray(border, np.uint8)
+    f = lib().orc_warp_perspective
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                  C.c_void_p, C.c_int, C.c_void_p]
+    f(img.ctypes.data, w * ch, w, h, ch, out.ctypes.data, ow * ch, ow, oh, m.ctypes.data, 1 if bilinear else 0, b.ctypes.data)
+    return out

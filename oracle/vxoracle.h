@@ -99,6 +99,12 @@ uint32_t orc_find_homography(const float *src, const float *dst, uint32_t n, flo
                              float outlier_ratio, float *H_out, uint8_t *mask);
 uint32_t orc_homography_hypotheses(float confidence, float outlier_ratio, uint32_t max_estimate_iters);
 
+/* vxWarpPerspectiveNode: demos/video_stabilizer/stabilizer.cpp:292-295.  m: 9 floats, row-major M of
+ * (x0,y0,z0) = M (x,y,1); channels 1 (U8) or 4 (RGBX); border: `channels` bytes.  Policies: vxoracle_homography.c. */
+void orc_warp_perspective(const uint8_t *src, uint32_t src_pitch, uint32_t sw, uint32_t sh, uint32_t channels,
+                          uint8_t *dst, uint32_t dst_pitch, uint32_t dw, uint32_t dh,
+                          const float *m, int bilinear, const uint8_t *border);
+
 #ifdef __cplusplus
 }
 #endif

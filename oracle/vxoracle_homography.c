@@ -320,3 +320,55 @@ uint32_t orc_find_homography(const float *src, const float *dst, uint32_t n, flo
         for (int c = 0; c < 3; ++c) H_out[3 * c + r] = H[3 * r + c];
     return best_cnt;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * vxWarpPerspectiveNode.  Call site: demos/video_stabilizer/stabilizer.cpp:292-295 (RGBX frame, BILINEAR, default
+ * border), matrix produced by truncate_transform_node.cpp:163-165.
+ * [S] output(x,y) = input(x0/z0, y0/z0), (x0,y0,z0) = M (x,y,1); `m` here is M row-major, i.e. m[3r+c] is element
+ *     [3c+r] of the vx_matrix data (OpenVX keeps the matrix column by column).
+ * [P] binary32: X = fma(m0,x,fma(m1,y,m2)) etc., xs = X/Z, ys = Y/Z (IEEE division);
+ *     BILINEAR: sampled where 0 <= xs <= w-1 and 0 <= ys <= h-1 (anything else, NaN included, takes the border value);
+ *       taps (floor, min(floor+1, size-1)); per channel top = fma(fx, p01-p00, p00), bot likewise,
+ *       v = fma(fy, bot-top, top), stored as (int)(v + 0.5);
+ *     NEAREST_NEIGHBOR: tap (floor(xs+0.5), floor(ys+0.5)) where that lies inside the image;
+ *     border: the constant `border` pixel (VX_BORDER_UNDEFINED is refined to constant 0).
+ */
+void orc_warp_perspective(const uint8_t *src, uint32_t src_pitch, uint32_t sw, uint32_t sh, uint32_t channels,
+                          uint8_t *dst, uint32_t dst_pitch, uint32_t dw, uint32_t dh,
+                          const float *m, int bilinear, const uint8_t *border)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (uint32_t y = 0; y < dh; ++y) {
+        uint8_t *o = dst + (size_t)y * dst_pitch;
+        for (uint32_t x = 0; x < dw; ++x) {
+            const float xf = (float)x, yf = (float)y;
+            const float X = fmaf(m[0], xf, fmaf(m[1], yf, m[2]));
+            const float Y = fmaf(m[3], xf, fmaf(m[4], yf, m[5]));
+            const float Z = fmaf(m[6], xf, fmaf(m[7], yf, m[8]));
+            const float xs = X / Z, ys = Y / Z;
+            for (uint32_t c = 0; c < channels; ++c) o[channels * x + c] = border[c];
+            if (bilinear) {
+                if (!(xs >= 0.0f && ys >= 0.0f && xs <= (float)(sw - 1) && ys <= (float)(sh - 1))) continue;
+                const float x0f = floorf(xs), y0f = floorf(ys);
+                const float fx = xs - x0f, fy = ys - y0f;
+                const uint32_t x0 = (uint32_t)x0f, y0 = (uint32_t)y0f;
+                const uint32_t x1 = x0 + 1 < sw ? x0 + 1 : sw - 1, y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
+                const uint8_t *r0 = src + (size_t)y0 * src_pitch, *r1 = src + (size_t)y1 * src_pitch;
+                for (uint32_t c = 0; c < channels; ++c) {
+                    const float a = r0[channels * x0 + c], b = r0[channels * x1 + c];
+                    const float cc = r1[channels * x0 + c], d = r1[channels * x1 + c];
+                    const float top = fmaf(fx, b - a, a), bot = fmaf(fx, d - cc, cc);
+                    const float v = fmaf(fy, bot - top, top);
+                    o[channels * x + c] = (uint8_t)(int)(v + 0.5f);
+                }
+            } else {
+                const float xr = floorf(xs + 0.5f), yr = floorf(ys + 0.5f);
+                if (!(xr >= 0.0f && yr >= 0.0f && xr <= (float)(sw - 1) && yr <= (float)(sh - 1))) continue;
+                const uint8_t *r = src + (size_t)(uint32_t)yr * src_pitch;
+                for (uint32_t c = 0; c < channels; ++c) o[channels * x + c] = r[channels * (uint32_t)xr + c];
+            }
+        }
+    }
+}

@@ -13,6 +13,8 @@
 //   ovxio::createDefaultRender(context, title, w, h, ...)   nvxio/include/OVX/RenderOVX.hpp:380
 //       records what the demo draws instead of drawing it: every putArrows(old, new) appends
 //       u32 n_old, n_old x {f32 x,y}, u32 n_new, n_new x {f32 x,y} to $VSA_HEADLESS_OUT (if set);
+//       every putImage(image) appends u32 width, u32 height and the packed RGBX (or U8) pixels to
+//       $VSA_HEADLESS_IMAGES (if set) -- what demos/video_stabilizer/main_video_stabilizer.cpp:291 would show;
 //       flush() returns false -- which ends the demo's loop (main_feature_tracker.cpp:385-388) --
 //       after $VSA_HEADLESS_FRAMES flushes (default 10).
 #include <cstdio>
@@ -108,10 +110,27 @@ public:
     {
         if (const char *e = getenv("VSA_HEADLESS_FRAMES")) frames_ = atoi(e);
         if (const char *o = getenv("VSA_HEADLESS_OUT")) out_.open(o, std::ios::binary);
+        if (const char *o = getenv("VSA_HEADLESS_IMAGES")) images_.open(o, std::ios::binary);
     }
     void setOnKeyboardEventCallback(OnKeyboardEventCallback, void *) override {}
     void setOnMouseEventCallback(OnMouseEventCallback, void *) override {}
-    void putImage(vx_image) override {}
+    void putImage(vx_image image) override
+    {
+        if (!images_.is_open()) return;
+        vx_uint32 w = 0, h = 0;
+        vx_df_image fmt = VX_DF_IMAGE_VIRT;
+        NVXIO_SAFE_CALL( vxQueryImage(image, VX_IMAGE_ATTRIBUTE_WIDTH, &w, sizeof(w)) );
+        NVXIO_SAFE_CALL( vxQueryImage(image, VX_IMAGE_ATTRIBUTE_HEIGHT, &h, sizeof(h)) );
+        NVXIO_SAFE_CALL( vxQueryImage(image, VX_IMAGE_ATTRIBUTE_FORMAT, &fmt, sizeof(fmt)) );
+        const vx_uint32 bpp = fmt == VX_DF_IMAGE_RGBX ? 4u : 1u;
+        std::vector<unsigned char> px((size_t)w * h * bpp);
+        vx_imagepatch_addressing_t addr = {};
+        addr.dim_x = w; addr.dim_y = h; addr.stride_x = (vx_int32)bpp; addr.stride_y = (vx_int32)(w * bpp);
+        NVXIO_SAFE_CALL( vxCopyImagePatch(image, nullptr, 0, &addr, px.data(), VX_READ_ONLY, VX_MEMORY_TYPE_HOST) );
+        images_.write(reinterpret_cast<const char *>(&w), 4);
+        images_.write(reinterpret_cast<const char *>(&h), 4);
+        images_.write(reinterpret_cast<const char *>(px.data()), (std::streamsize)px.size());
+    }
     void putTextViewport(const std::string &, const TextBoxStyle &) override {}
     void putFeatures(vx_array, const FeatureStyle &) override {}
     void putFeatures(vx_array, vx_array) override {}
@@ -127,7 +146,7 @@ public:
         writePoints(new_points);
     }
     bool flush() override { return ++flushed_ < frames_; }
-    void close() override { out_.close(); }
+    void close() override { out_.close(); images_.close(); }
     vx_uint32 getViewportWidth() const override { return w_; }
     vx_uint32 getViewportHeight() const override { return h_; }
 
@@ -144,7 +163,7 @@ private:
     }
     vx_uint32 w_, h_;
     int frames_ = 10, flushed_ = 0;
-    std::ofstream out_;
+    std::ofstream out_, images_;
 };
 
 }  // namespace

@@ -393,3 +393,249 @@ def test_tracker_graph_feeding_homography_orders_after_lk(ctx):
     order = _order(ft["g"])
     assert order.index(ovx.K_FIND_HOMOGRAPHY) > order.index(ovx.K_PYRLK)
     assert order[:3] == [ovx.K_COLOR_CONVERT, ovx.K_GAUSSIAN_PYRAMID, ovx.K_PYRLK]
+
+
+# ---- user kernels, generic nodes, delays of matrices, uniform / ROI images (video stabilizer) ----------
+_KEEP = []   # ctypes callbacks must outlive the contexts that hold them
+
+
+def _add_kernel(ctx, name, func, nparams, validate=None, params=()):
+    kid = C.c_int32()
+    assert L.vxAllocateUserKernelId(ctx, C.byref(kid)) == ovx.VX_SUCCESS
+    f = ovx.KERNEL_F(func)
+    v = ovx.VALIDATE_F(validate) if validate else C.cast(None, ovx.VALIDATE_F)
+    none_f = C.cast(None, ovx.KERNEL_F)
+    _KEEP.extend([f, v])
+    k = L.vxAddUserKernel(ctx, name.encode(), kid.value, f, nparams, v, none_f, none_f)
+    assert L.vxGetStatus(k) == ovx.VX_SUCCESS
+    for i, (d, t) in enumerate(params):
+        assert L.vxAddParameterToKernel(k, i, d, t, ovx.VX_PARAMETER_STATE_REQUIRED) == ovx.VX_SUCCESS
+    return k, kid.value
+
+
+def test_user_kernel_registration(ctx):
+    """the sequence of demos/video_stabilizer/homography_filter_node.cpp:205-256"""
+    k, kid = _add_kernel(ctx, "example.test.a", lambda n, p, c: 0, 2,
+                         params=[(ovx.VX_INPUT, ovx.VX_TYPE_MATRIX)])
+    assert L.vxGetStatus(L.vxGetKernelByName(ctx, b"example.test.a")) != ovx.VX_SUCCESS      # not finalized yet
+    assert L.vxFinalizeKernel(k) == ovx.VX_ERROR_INVALID_PARAMETERS                           # parameter 1 undescribed
+    g = L.vxCreateGraph(ctx)
+    assert L.vxGetStatus(L.vxCreateGenericNode(g, k)) == ovx.VX_ERROR_INVALID_REFERENCE
+    assert L.vxAddParameterToKernel(k, 1, ovx.VX_OUTPUT, ovx.VX_TYPE_MATRIX, ovx.VX_PARAMETER_STATE_REQUIRED) == ovx.VX_SUCCESS
+    assert L.vxAddParameterToKernel(k, 2, ovx.VX_OUTPUT, ovx.VX_TYPE_MATRIX, ovx.VX_PARAMETER_STATE_REQUIRED) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxAddParameterToKernel(k, 1, 0x1234, ovx.VX_TYPE_MATRIX, ovx.VX_PARAMETER_STATE_REQUIRED) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxFinalizeKernel(k) == ovx.VX_SUCCESS
+    assert L.vxAddParameterToKernel(k, 1, ovx.VX_OUTPUT, ovx.VX_TYPE_MATRIX, ovx.VX_PARAMETER_STATE_REQUIRED) == ovx.VX_ERROR_NOT_SUPPORTED
+    assert ovx.query("vxQueryKernel", k, ovx.VX_KERNEL_PARAMETERS, C.c_uint32) == 2
+    assert ovx.query("vxQueryKernel", k, ovx.VX_KERNEL_ENUM, C.c_int32) == kid
+    name = C.create_string_buffer(256)
+    assert L.vxQueryKernel(k, ovx.VX_KERNEL_NAME, name, 256) == ovx.VX_SUCCESS and name.value == b"example.test.a"
+    assert ovx.release("Kernel", k) == ovx.VX_SUCCESS            # the registry keeps it (homography_filter_node.cpp:247)
+    k2 = L.vxGetKernelByName(ctx, b"example.test.a")
+    assert k2 == k and L.vxGetStatus(k2) == ovx.VX_SUCCESS
+    assert L.vxGetKernelByEnum(ctx, kid) == k
+    assert ovx.release("Kernel", k) == ovx.VX_SUCCESS
+    # a second kernel gets a different id; a taken name is refused
+    _, kid2 = _add_kernel(ctx, "example.test.b", lambda n, p, c: 0, 1, params=[(ovx.VX_INPUT, ovx.VX_TYPE_IMAGE)])
+    assert kid2 != kid
+    f = ovx.KERNEL_F(lambda n, p, c: 0)
+    _KEEP.append(f)
+    none_f, none_v = C.cast(None, ovx.KERNEL_F), C.cast(None, ovx.VALIDATE_F)
+    assert L.vxGetStatus(L.vxAddUserKernel(ctx, b"example.test.a", kid2 + 1, f, 1, none_v, none_f, none_f)) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxGetStatus(L.vxAddUserKernel(ctx, b"", kid2 + 1, f, 1, none_v, none_f, none_f)) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxGetStatus(L.vxAddUserKernel(ctx, b"x", kid2 + 1, f, 0, none_v, none_f, none_f)) == ovx.VX_ERROR_INVALID_PARAMETERS
+    # removal takes it out of the registry
+    assert L.vxRemoveKernel(L.vxGetKernelByName(ctx, b"example.test.a")) == ovx.VX_SUCCESS
+    assert L.vxGetStatus(L.vxGetKernelByName(ctx, b"example.test.a")) != ovx.VX_SUCCESS
+
+
+def test_user_node_verification(ctx):
+    """vxCreateGenericNode + vxSetParameterByIndex + the validator's meta formats (homography_filter_node.cpp:162-202,259-280)"""
+    seen = []
+    meta_rows = [3]
+
+    def validate(node, params, num, metas):
+        seen.append(("validate", num, params[0], params[1]))
+        t, r, c = C.c_int32(ovx.VX_TYPE_FLOAT32), C.c_size_t(meta_rows[0]), C.c_size_t(3)
+        L.vxSetMetaFormatAttribute(metas[1], ovx.VX_MATRIX_TYPE, C.byref(t), 4)
+        L.vxSetMetaFormatAttribute(metas[1], ovx.VX_MATRIX_ROWS, C.byref(r), 8)
+        L.vxSetMetaFormatAttribute(metas[1], ovx.VX_MATRIX_COLUMNS, C.byref(c), 8)
+        rows = ovx.query("vxQueryMatrix", params[0], ovx.VX_MATRIX_ROWS, C.c_size_t)
+        return ovx.VX_SUCCESS if rows == 3 else ovx.VX_ERROR_INVALID_PARAMETERS
+
+    k, _ = _add_kernel(ctx, "example.test.filter", lambda n, p, c: 0, 2, validate,
+                       [(ovx.VX_INPUT, ovx.VX_TYPE_MATRIX), (ovx.VX_OUTPUT, ovx.VX_TYPE_MATRIX)])
+    assert L.vxFinalizeKernel(k) == ovx.VX_SUCCESS
+    g = L.vxCreateGraph(ctx)
+    n = L.vxCreateGenericNode(g, k)
+    assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_PARAMETERS and not seen        # required parameters unset
+    a, b = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3), L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    img = L.vxCreateImage(ctx, 8, 8, ovx.VX_DF_IMAGE_U8)
+    assert L.vxSetParameterByIndex(n, 0, img) == ovx.VX_ERROR_INVALID_REFERENCE      # the kernel says: a matrix
+    assert L.vxSetParameterByIndex(n, 0, a) == ovx.VX_SUCCESS
+    assert L.vxSetParameterByIndex(n, 1, b) == ovx.VX_SUCCESS
+    assert L.vxSetParameterByIndex(n, 2, b) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    assert seen == [("validate", 2, a, b)]
+    assert _order(g) == [ovx.K_USER]
+    assert L.vxProcessGraph(g) == ovx.NVX_ERROR_NO_GPU                               # graphs need the device, host nodes included
+    # the output disagrees with what the validator announced
+    meta_rows[0] = 2
+    assert L.vxSetParameterByIndex(n, 1, L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_PARAMETERS
+    meta_rows[0] = 3
+    # the validator's own verdict is the graph's
+    assert L.vxSetParameterByIndex(n, 0, L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 2)) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_PARAMETERS
+
+
+def test_stabilizer_graph_shape_orders_by_data(ctx):
+    """the node set of demos/video_stabilizer/stabilizer.cpp:228-316 with Python stand-ins for the three user kernels:
+    order follows the data, the delay parameter standing for every slot of the delay"""
+    specs = {
+        "filter": [(ovx.VX_INPUT, ovx.VX_TYPE_MATRIX), (ovx.VX_OUTPUT, ovx.VX_TYPE_MATRIX), (ovx.VX_INPUT, ovx.VX_TYPE_IMAGE), (ovx.VX_INPUT, ovx.VX_TYPE_ARRAY)],
+        "smoother": [(ovx.VX_INPUT, ovx.VX_TYPE_DELAY), (ovx.VX_OUTPUT, ovx.VX_TYPE_MATRIX)],
+        "truncate": [(ovx.VX_INPUT, ovx.VX_TYPE_MATRIX), (ovx.VX_OUTPUT, ovx.VX_TYPE_MATRIX), (ovx.VX_INPUT, ovx.VX_TYPE_IMAGE), (ovx.VX_INPUT, ovx.VX_TYPE_SCALAR)],
+    }
+    kernels = {}
+    for name, sp in specs.items():
+        k, _ = _add_kernel(ctx, "example.shape." + name, lambda n, p, c: 0, len(sp), None, sp)
+        assert L.vxFinalizeKernel(k) == ovx.VX_SUCCESS
+        kernels[name] = k
+    w, h, cap = 320, 240, 1000
+    frame = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+    pex = L.vxCreatePyramid(ctx, 4, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
+    pyr_delay = L.vxCreateDelay(ctx, pex, 2)
+    aex = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, cap)
+    pts_delay = L.vxCreateDelay(ctx, aex, 2)
+    smoothed = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    mat_delay = L.vxCreateDelay(ctx, smoothed, 11)
+    assert L.vxGetStatus(mat_delay) == ovx.VX_SUCCESS
+    assert ovx.query("vxQueryDelay", mat_delay, ovx.VX_DELAY_TYPE, C.c_int32) == ovx.VX_TYPE_MATRIX
+    frames_delay = L.vxCreateDelay(ctx, frame, 7)
+    stabilized = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+    g = L.vxCreateGraph(ctx)
+    gray = L.vxCreateVirtualImage(g, 0, 0, ovx.VX_DF_IMAGE_U8)
+    kp = L.vxCreateVirtualArray(g, ovx.NVX_TYPE_POINT2F, cap)
+    mask = L.vxCreateVirtualArray(g, ovx.VX_TYPE_UINT8, cap)
+    homography = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    truncated = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    eps, it, est = ovx.scalar(ctx, ovx.VX_TYPE_FLOAT32, 0.01), ovx.scalar(ctx, ovx.VX_TYPE_UINT32, 5), ovx.scalar(ctx, ovx.VX_TYPE_BOOL, 0)
+    margin = ovx.scalar(ctx, ovx.VX_TYPE_FLOAT32, 0.05)
+
+    def generic(name, *params):
+        n = L.vxCreateGenericNode(g, kernels[name])
+        assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+        for i, p in enumerate(params):
+            assert L.vxSetParameterByIndex(n, i, p) == ovx.VX_SUCCESS
+        return n
+
+    # created in an order that is NOT the execution order
+    nodes = [
+        L.vxWarpPerspectiveNode(g, L.vxGetReferenceFromDelay(frames_delay, -6), truncated, ovx.VX_INTERPOLATION_BILINEAR, stabilized),
+        generic("truncate", smoothed, truncated, frame, margin),
+        generic("smoother", mat_delay, smoothed),
+        generic("filter", homography, L.vxGetReferenceFromDelay(mat_delay, 0), frame, mask),
+        L.nvxFindHomographyNode(g, L.vxGetReferenceFromDelay(pts_delay, -1), kp, homography,
+                                ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, mask),
+        L.nvxHarrisTrackNode(g, gray, L.vxGetReferenceFromDelay(pts_delay, 0), None, kp, 0.04, 100.0, 18, None),
+        L.vxOpticalFlowPyrLKNode(g, L.vxGetReferenceFromDelay(pyr_delay, -1), L.vxGetReferenceFromDelay(pyr_delay, 0),
+                                 L.vxGetReferenceFromDelay(pts_delay, -1), L.vxGetReferenceFromDelay(pts_delay, -1),
+                                 kp, ovx.VX_TERM_CRITERIA_BOTH, eps, it, est, 10),
+        L.vxGaussianPyramidNode(g, gray, L.vxGetReferenceFromDelay(pyr_delay, 0)),
+        L.nvxCopyImageNode(g, frame, L.vxGetReferenceFromDelay(frames_delay, 0)),
+        L.vxColorConvertNode(g, frame, gray),
+    ]
+    for n in nodes:
+        assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    buf = (C.c_int * 16)()
+    order = list(buf[:L.visualslam_amd_graph_order(g, buf, 16)])
+    assert len(order) == 10
+    pos = {k: [i for i, x in enumerate(order) if x == k] for k in set(order)}
+    assert pos[ovx.K_COLOR_CONVERT][0] < pos[ovx.K_GAUSSIAN_PYRAMID][0] < pos[ovx.K_PYRLK][0] < pos[ovx.K_FIND_HOMOGRAPHY][0]
+    users = pos[ovx.K_USER]
+    assert len(users) == 3 and pos[ovx.K_FIND_HOMOGRAPHY][0] < users[0] and users[2] < pos[ovx.K_WARP_PERSPECTIVE][0]
+    assert pos[ovx.K_PYRLK][0] < pos[ovx.K_HARRIS_TRACK][0]
+    assert ovx.query("vxQueryImage", gray, ovx.VX_IMAGE_WIDTH, C.c_uint32) == w
+
+
+def test_delay_of_matrices(ctx):
+    """stabilizer.cpp:357-375,438: slots are clones of the exemplar, written and aged independently"""
+    import numpy as np
+    ex = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    seed = np.arange(9, dtype=np.float32)
+    assert L.vxCopyMatrix(ex, seed.ctypes.data, ovx.VX_WRITE_ONLY, ovx.VX_MEMORY_TYPE_HOST) == 0
+    d = L.vxCreateDelay(ctx, ex, 3)
+    ovx.release("Matrix", ex)
+    slots = [L.vxGetReferenceFromDelay(d, -i) for i in range(3)]
+    got = np.zeros(9, np.float32)
+    for i, s in enumerate(slots):
+        assert L.vxCopyMatrix(s, got.ctypes.data, ovx.VX_READ_ONLY, ovx.VX_MEMORY_TYPE_HOST) == 0 and (got == seed).all()
+        v = np.full(9, float(i), np.float32)
+        assert L.vxCopyMatrix(s, v.ctypes.data, ovx.VX_WRITE_ONLY, ovx.VX_MEMORY_TYPE_HOST) == 0
+    assert L.vxAgeDelay(d) == ovx.VX_SUCCESS
+    vals = []
+    for s in slots:                                # what was at 0 is at -1, -1 at -2, the oldest wraps to 0
+        L.vxCopyMatrix(s, got.ctypes.data, ovx.VX_READ_ONLY, ovx.VX_MEMORY_TYPE_HOST)
+        vals.append(float(got[0]))
+    assert vals == [2.0, 0.0, 1.0]
+
+
+def test_uniform_and_roi_images(ctx):
+    """stabilizer.cpp:399-404 (vxCreateUniformImage), main_video_stabilizer.cpp:225-235 (valid region, ROI views)"""
+    px = ovx.vx_pixel_value_t()
+    px.RGBX[:] = [1, 2, 3, 4]
+    u = L.vxCreateUniformImage(ctx, 64, 32, ovx.VX_DF_IMAGE_RGBX, C.byref(px))
+    assert L.vxGetStatus(u) == ovx.VX_SUCCESS and ovx.query("vxQueryImage", u, ovx.VX_IMAGE_WIDTH, C.c_uint32) == 64
+    assert L.vxGetStatus(L.vxCreateUniformImage(ctx, 64, 32, ovx.VX_DF_IMAGE_RGBX, None)) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxGetStatus(L.vxCreateUniformImage(ctx, 0, 32, ovx.VX_DF_IMAGE_RGBX, C.byref(px))) == ovx.VX_ERROR_INVALID_DIMENSION
+    r = ovx.vx_rectangle_t()
+    assert L.vxGetValidRegionImage(u, C.byref(r)) == ovx.VX_SUCCESS
+    assert (r.start_x, r.start_y, r.end_x, r.end_y) == (0, 0, 64, 32)
+    left = L.vxCreateImageFromROI(u, C.byref(ovx.vx_rectangle_t(0, 0, 32, 32)))
+    right = L.vxCreateImageFromROI(u, C.byref(ovx.vx_rectangle_t(32, 0, 64, 32)))
+    for v in (left, right):
+        assert L.vxGetStatus(v) == ovx.VX_SUCCESS
+        assert ovx.query("vxQueryImage", v, ovx.VX_IMAGE_WIDTH, C.c_uint32) == 32
+        assert ovx.query("vxQueryImage", v, ovx.VX_IMAGE_FORMAT, C.c_uint32) == ovx.VX_DF_IMAGE_RGBX
+    assert ovx.query("vxQueryReference", u, ovx.VX_REFERENCE_COUNT, C.c_uint32) == 3          # the views keep the parent
+    assert L.vxGetStatus(L.vxCreateImageFromROI(u, C.byref(ovx.vx_rectangle_t(32, 0, 65, 32)))) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxGetStatus(L.vxCreateImageFromROI(u, C.byref(ovx.vx_rectangle_t(5, 5, 5, 9)))) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert ovx.release("Image", u) == ovx.VX_SUCCESS                                           # views outlive the handle
+    assert ovx.query("vxQueryImage", left, ovx.VX_IMAGE_HEIGHT, C.c_uint32) == 32
+    # two nodes writing two views of one image cannot be ordered by data: the graph is refused
+    g = L.vxCreateGraph(ctx)
+    a = L.vxCreateImage(ctx, 32, 32, ovx.VX_DF_IMAGE_RGBX)
+    L.nvxCopyImageNode(g, a, left)
+    L.nvxCopyImageNode(g, a, L.vxCreateImageFromROI(left, C.byref(ovx.vx_rectangle_t(0, 0, 32, 32))))
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_GRAPH
+
+
+def test_warp_perspective_node_verification(ctx):
+    a = L.vxCreateImage(ctx, 64, 48, ovx.VX_DF_IMAGE_RGBX)
+    b = L.vxCreateImage(ctx, 64, 48, ovx.VX_DF_IMAGE_RGBX)
+    u8 = L.vxCreateImage(ctx, 64, 48, ovx.VX_DF_IMAGE_U8)
+    m = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+    m23 = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 2, 3)
+
+    def verify(*args):
+        g = L.vxCreateGraph(ctx)
+        n = L.vxWarpPerspectiveNode(g, *args)
+        return n, (L.vxVerifyGraph(g) if L.vxGetStatus(n) == ovx.VX_SUCCESS else L.vxGetStatus(n))
+
+    n, st = verify(a, m, ovx.VX_INTERPOLATION_BILINEAR, b)
+    assert st == ovx.VX_SUCCESS
+    bd = ovx.vx_border_t(ovx.VX_BORDER_CONSTANT, (C.c_uint8 * 4)(9, 8, 7, 6))
+    assert L.vxSetNodeAttribute(n, ovx.VX_NODE_BORDER, C.byref(bd), C.sizeof(bd)) == ovx.VX_SUCCESS
+    back = ovx.vx_border_t()
+    assert L.vxQueryNode(n, ovx.VX_NODE_BORDER, C.byref(back), C.sizeof(back)) == 0 and list(back.constant_value) == [9, 8, 7, 6]
+    bd.mode = ovx.VX_BORDER_REPLICATE
+    assert L.vxSetNodeAttribute(n, ovx.VX_NODE_BORDER, C.byref(bd), C.sizeof(bd)) == ovx.VX_ERROR_NOT_SUPPORTED
+    assert verify(a, m, ovx.VX_INTERPOLATION_NEAREST_NEIGHBOR, b)[1] == ovx.VX_SUCCESS
+    assert verify(a, m, ovx.VX_INTERPOLATION_AREA, b)[1] == ovx.VX_ERROR_NOT_SUPPORTED
+    assert verify(a, m, ovx.VX_INTERPOLATION_BILINEAR, u8)[1] == ovx.VX_ERROR_INVALID_FORMAT
+    assert verify(a, m23, ovx.VX_INTERPOLATION_BILINEAR, b)[1] == ovx.VX_ERROR_INVALID_DIMENSION
+    assert verify(a, None, ovx.VX_INTERPOLATION_BILINEAR, b)[1] == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxuWarpPerspective(ctx, a, m, ovx.VX_INTERPOLATION_BILINEAR, b) == ovx.NVX_ERROR_NO_GPU

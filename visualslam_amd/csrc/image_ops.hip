@@ -177,7 +177,94 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_fused(PyrFusedArgs a)
                              ox[NS], oy[NS], T, tid);
 }
 
+
+// ---- perspective warp ------------------------------------------------------------------------------
+// output(x,y) = input(X/Z, Y/Z), (X,Y,Z) = M (x,y,1).  One thread per output pixel, 64x4 tiles dealt to the XCDs in
+// contiguous bands of rows (near-identity warps then re-read their taps from one L2).  Arithmetic and its order:
+// oracle/vxoracle_homography.c (warp perspective) -- results are bit-identical.
+struct WarpArgs {
+    const uint8_t *src;
+    uint32_t src_pitch;
+    int sw, sh;
+    uint8_t *dst;
+    uint32_t dst_pitch;
+    int dw, dh;
+    float m[9];
+    int bilinear;
+    uint32_t border;      // constant border pixel (U8: low byte)
+    uint32_t tiles_x, tiles;
+};
+
+template <int CH>
+__device__ __forceinline__ uint32_t warp_fetch(const uint8_t *row, int x)
+{
+    return CH == 4 ? reinterpret_cast<const uint32_t *>(row)[x] : (uint32_t)row[x];
+}
+
+__device__ __forceinline__ uint32_t warp_lerp_channel(uint32_t p00, uint32_t p01, uint32_t p10, uint32_t p11, int shift, float fx, float fy)
+{
+    const float a = (float)((p00 >> shift) & 0xffu), b = (float)((p01 >> shift) & 0xffu);
+    const float c = (float)((p10 >> shift) & 0xffu), d = (float)((p11 >> shift) & 0xffu);
+    const float top = fmaf(fx, b - a, a), bot = fmaf(fx, d - c, c);
+    const float v = fmaf(fy, bot - top, top);
+    return ((uint32_t)(int)(v + 0.5f)) << shift;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_warp_perspective(WarpArgs a)
+{
+    const uint32_t item = xcd_contiguous_item(blockIdx.x, a.tiles);
+    const int x = (int)((item % a.tiles_x) * 64u + threadIdx.x), y = (int)((item / a.tiles_x) * 4u + threadIdx.y);
+    if (x >= a.dw || y >= a.dh) return;
+    const float xf = (float)x, yf = (float)y;
+    const float X = fmaf(a.m[0], xf, fmaf(a.m[1], yf, a.m[2]));
+    const float Y = fmaf(a.m[3], xf, fmaf(a.m[4], yf, a.m[5]));
+    const float Z = fmaf(a.m[6], xf, fmaf(a.m[7], yf, a.m[8]));
+    const float xs = X / Z, ys = Y / Z;
+    uint32_t out = a.border;
+    if (a.bilinear) {
+        if (xs >= 0.0f && ys >= 0.0f && xs <= (float)(a.sw - 1) && ys <= (float)(a.sh - 1)) {   // false for NaN
+            const float x0f = floorf(xs), y0f = floorf(ys);
+            const float fx = xs - x0f, fy = ys - y0f;
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const int x1 = min(x0 + 1, a.sw - 1), y1 = min(y0 + 1, a.sh - 1);
+            const uint8_t *r0 = a.src + (size_t)y0 * a.src_pitch, *r1 = a.src + (size_t)y1 * a.src_pitch;
+            const uint32_t p00 = warp_fetch<CH>(r0, x0), p01 = warp_fetch<CH>(r0, x1);
+            const uint32_t p10 = warp_fetch<CH>(r1, x0), p11 = warp_fetch<CH>(r1, x1);
+            out = 0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) out |= warp_lerp_channel(p00, p01, p10, p11, 8 * c, fx, fy);
+        }
+    } else {
+        const float xr = floorf(xs + 0.5f), yr = floorf(ys + 0.5f);
+        if (xr >= 0.0f && yr >= 0.0f && xr <= (float)(a.sw - 1) && yr <= (float)(a.sh - 1))
+            out = warp_fetch<CH>(a.src + (size_t)(int)yr * a.src_pitch, (int)xr);
+    }
+    uint8_t *o = a.dst + (size_t)y * a.dst_pitch;
+    if (CH == 4) reinterpret_cast<uint32_t *>(o)[x] = out;
+    else o[x] = (uint8_t)out;
+}
+
 }  // namespace
+
+hipError_t launch_warp_perspective(const WarpPerspectiveParams &p, hipStream_t stream)
+{
+    if (p.dst_width == 0 || p.dst_height == 0) return hipSuccess;
+    if (p.src.width == 0 || p.src.height == 0 || (p.channels != 1 && p.channels != 4)) return hipErrorInvalidValue;
+    if (p.channels == 4 && (((uintptr_t)p.src.ptr | (uintptr_t)p.dst | p.src.pitch | p.dst_pitch) & 3u)) return hipErrorInvalidValue;
+    WarpArgs a{};
+    a.src = p.src.ptr; a.src_pitch = p.src.pitch; a.sw = (int)p.src.width; a.sh = (int)p.src.height;
+    a.dst = p.dst; a.dst_pitch = p.dst_pitch; a.dw = (int)p.dst_width; a.dh = (int)p.dst_height;
+    for (int i = 0; i < 9; ++i) a.m[i] = p.m[i];
+    a.bilinear = p.bilinear ? 1 : 0;
+    a.border = p.border;
+    a.tiles_x = (p.dst_width + 63u) / 64u;
+    a.tiles = a.tiles_x * ((p.dst_height + 3u) / 4u);
+    const dim3 block(64, 4);
+    if (p.channels == 4) hipLaunchKernelGGL(k_warp_perspective<4>, dim3(a.tiles), block, 0, stream, a);
+    else hipLaunchKernelGGL(k_warp_perspective<1>, dim3(a.tiles), block, 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_rgbx_to_u8(const ImageView &src, uint8_t *dst, uint32_t dst_pitch, hipStream_t stream)
 {

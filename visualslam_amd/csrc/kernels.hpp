@@ -52,6 +52,19 @@ hipError_t launch_rgbx_to_u8(const ImageView &src, uint8_t *dst, uint32_t dst_pi
 // w = [1 4 6 4 1]; up to four steps fused per launch
 hipError_t launch_gaussian_pyramid(const PyramidView &pyr, hipStream_t stream);
 
+// output(x,y) = input(X/Z, Y/Z) with (X,Y,Z) = m (x,y,1), m row-major; U8 (channels 1) or RGBX (channels 4, 4-byte
+// aligned); bilinear or nearest neighbour; samples outside the input take `border`
+struct WarpPerspectiveParams {
+    ImageView src;
+    uint8_t *dst;
+    uint32_t dst_pitch, dst_width, dst_height;
+    uint32_t channels;
+    float m[9];
+    bool bilinear;
+    uint32_t border;
+};
+hipError_t launch_warp_perspective(const WarpPerspectiveParams &p, hipStream_t stream);
+
 struct CornerTrackParams {
     Detector detector;
     ImageView image;

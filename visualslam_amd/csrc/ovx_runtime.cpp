@@ -54,6 +54,7 @@ struct MapRecord {
     size_t x0, y0, w, h;              // image rect (bytes are w*bpp) or array range [x0, x0+w)
 };
 
+struct _vx_kernel;
 struct _vx_context : _vx_reference {
     int device = -1;
     bool no_device = false;           // host-logic-only mode (tests): objects exist, nothing can run
@@ -69,6 +70,8 @@ struct _vx_context : _vx_reference {
     uint32_t *pinned = nullptr;       // 16 dwords of pinned host memory for count read-backs
     void *scratch = nullptr;          // immediate-mode detector scratch
     size_t scratch_size = 0;
+    std::map<std::string, _vx_kernel *> kernels;   // finalized user kernels by name (the registry holds a reference)
+    vx_enum next_kernel_id = VX_KERNEL_BASE(VX_ID_DEFAULT, 0) + 0x100;
 };
 
 struct _vx_image : _vx_reference {
@@ -78,6 +81,10 @@ struct _vx_image : _vx_reference {
     uint8_t *dev = nullptr;
     uint32_t pitch = 0;
     _vx_pyramid *pyramid = nullptr;   // set for pyramid levels (dependency analysis)
+    _vx_image *parent = nullptr;      // vxCreateImageFromROI: a view of the parent's memory at (roi_x, roi_y)
+    uint32_t roi_x = 0, roi_y = 0;
+    bool has_fill = false;            // vxCreateUniformImage: written with `fill` when the memory is allocated
+    uint32_t fill = 0;
 };
 
 struct _vx_pyramid : _vx_reference {
@@ -94,6 +101,7 @@ struct _vx_array : _vx_reference {
     uint32_t *dev_count = nullptr;
     size_t num_items = 0;             // host mirror, refreshed after every operation that writes the array
     uint32_t *count_mirror = nullptr; // set while a graph is enqueued: pinned slot the writing kernel also stores the count to
+    bool mirror_pending = false;      // a kernel of the running graph has been enqueued that writes the count to count_mirror
 };
 
 struct _vx_scalar : _vx_reference {
@@ -109,6 +117,7 @@ struct _vx_matrix : _vx_reference {
     std::vector<uint8_t> host;        // the values as the application sees them (row-major)
     void *dev = nullptr;              // device copy, allocated when a node first writes or reads it
     float *mirror = nullptr;          // set while a graph is enqueued: pinned slots the writing kernel also stores to
+    bool mirror_pending = false;      // a kernel of the running graph has been enqueued that writes the values to `mirror`
 };
 
 struct _vx_delay : _vx_reference {
@@ -116,9 +125,28 @@ struct _vx_delay : _vx_reference {
     std::vector<_vx_reference *> slots;   // slots[i] <-> index -i
 };
 
-enum KernelKind { K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE, K_FIND_HOMOGRAPHY };
+enum KernelKind { K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE, K_FIND_HOMOGRAPHY,
+                  K_WARP_PERSPECTIVE, K_USER };
 
 struct ParamSpec { vx_enum dir; vx_enum type; bool optional; };
+
+// a user kernel: host callbacks the graph runs between its device nodes (video_stabilizer/*_node.cpp)
+struct _vx_kernel : _vx_reference {
+    std::string name;
+    vx_enum enumeration = 0;
+    vx_kernel_f func = nullptr;
+    vx_kernel_validate_f validate = nullptr;
+    vx_kernel_initialize_f init = nullptr;
+    vx_kernel_deinitialize_f deinit = nullptr;
+    std::vector<ParamSpec> spec;
+    std::vector<bool> spec_set;
+    bool finalized = false;
+};
+
+// what a validator says about one output: attribute -> value bytes, compared with the bound object at vxVerifyGraph
+struct _vx_meta_format : _vx_reference {
+    std::map<vx_enum, std::vector<uint8_t>> attrs;
+};
 
 struct _vx_node : _vx_reference {
     _vx_graph *graph = nullptr;
@@ -135,7 +163,11 @@ struct _vx_node : _vx_reference {
     size_t scratch_size = 0;
     size_t *dev_num_corners = nullptr;
     uint64_t *num_corners_mirror = nullptr;   // pinned slot the merge kernel also stores num_corners to (set per enqueue)
+    bool corners_pending = false;
     vx_status last_status = VX_SUCCESS;
+    _vx_kernel *kernel = nullptr;             // K_USER: the kernel (retained)
+    bool user_initialized = false;            // K_USER: the kernel's initializer has run for the current parameters
+    vx_border_t border{};                     // K_WARP_PERSPECTIVE: constant border value (mode UNDEFINED = constant 0)
 };
 
 struct _vx_graph : _vx_reference {
@@ -208,15 +240,26 @@ vx_status hip_status(hipError_t e) { return e == hipSuccess ? VX_SUCCESS : VX_FA
 // ---- device memory -----------------------------------------------------------------------------
 vx_status ensure_image(_vx_image *im)
 {
+    if (im->parent) {   // a view: the parent's memory at the ROI's origin (recomputed: the parent's memory may have moved)
+        vx_status s = ensure_image(im->parent);
+        if (s != VX_SUCCESS) return s;
+        im->pitch = im->parent->pitch;
+        im->dev = im->parent->dev + (size_t)im->roi_y * im->pitch + (size_t)im->roi_x * im->bpp;
+        return VX_SUCCESS;
+    }
     if (im->dev) return VX_SUCCESS;
     if (im->ctx->no_device) return (vx_status)NVX_ERROR_NO_GPU;
+    if (im->width == 0 || im->height == 0) return VX_ERROR_INVALID_DIMENSION;      // a virtual image nobody sized
     im->pitch = (im->width * im->bpp + kPitchAlign - 1) / kPitchAlign * kPitchAlign;
     void *p = nullptr;
-    if (hipMalloc(&p, (size_t)im->pitch * im->height + kRowSlack) != hipSuccess) return VX_ERROR_NO_MEMORY;
+    const size_t bytes = (size_t)im->pitch * im->height + kRowSlack;
+    if (hipMalloc(&p, bytes) != hipSuccess) return VX_ERROR_NO_MEMORY;
     // hipMemset is asynchronous on the null stream and our streams are non-blocking: finish it now,
     // or it could land after the first kernel that writes this image
-    if (hipMemset(p, 0, (size_t)im->pitch * im->height + kRowSlack) != hipSuccess ||
-        hipStreamSynchronize(nullptr) != hipSuccess) return VX_FAILURE;
+    hipError_t e = hipSuccess;
+    if (im->has_fill && im->bpp == 4) e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(p), (int)im->fill, bytes / 4);
+    else e = hipMemset(p, im->has_fill ? (int)(im->fill & 0xffu) : 0, bytes);
+    if (e != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(p); return VX_FAILURE; }
     im->dev = static_cast<uint8_t *>(p);
     return VX_SUCCESS;
 }
@@ -275,7 +318,8 @@ void destroy(_vx_reference *r)
     switch (r->type) {
     case VX_TYPE_IMAGE: {
         auto *im = static_cast<_vx_image *>(r);
-        if (im->dev) (void)hipFree(im->dev);
+        if (im->parent) release_ref(im->parent);
+        else if (im->dev) (void)hipFree(im->dev);
         break;
     }
     case VX_TYPE_PYRAMID: {
@@ -300,6 +344,10 @@ void destroy(_vx_reference *r)
     }
     case VX_TYPE_NODE: {
         auto *n = static_cast<_vx_node *>(r);
+        if (n->kernel) {
+            if (n->user_initialized && n->kernel->deinit) (void)n->kernel->deinit(n, n->params.data(), (vx_uint32)n->params.size());
+            release_ref(n->kernel);
+        }
         for (auto *p : n->params) release_ref(p);
         if (n->ev0) (void)hipEventDestroy(n->ev0);
         if (n->ev1) (void)hipEventDestroy(n->ev1);
@@ -331,6 +379,8 @@ void destroy(_vx_reference *r)
     case VX_TYPE_MATRIX: delete static_cast<_vx_matrix *>(r); break;
     case VX_TYPE_NODE: delete static_cast<_vx_node *>(r); break;
     case VX_TYPE_GRAPH: delete static_cast<_vx_graph *>(r); break;
+    case VX_TYPE_KERNEL: delete static_cast<_vx_kernel *>(r); break;
+    case VX_TYPE_META_FORMAT: delete static_cast<_vx_meta_format *>(r); break;
     default: delete r; break;
     }
 }
@@ -623,6 +673,36 @@ vx_status do_find_homography(_vx_array *src, _vx_array *dst, _vx_matrix *mat, vx
     return hip_status(launch_find_homography(p, stream));
 }
 
+// the matrix as stored is M column by column: data[3c + r] = M[r][c] (truncate_transform_node.cpp:163-165)
+vx_status do_warp_perspective(_vx_image *in, _vx_matrix *mat, vx_enum interp, _vx_image *out, const vx_border_t &border,
+                              hipStream_t stream)
+{
+    if (!in || !mat || !out) return VX_ERROR_INVALID_PARAMETERS;
+    if (in->format != out->format || (in->format != VX_DF_IMAGE_U8 && in->format != VX_DF_IMAGE_RGBX)) return VX_ERROR_INVALID_FORMAT;
+    if (mat->data_type != VX_TYPE_FLOAT32 || mat->cols != 3 || mat->rows != 3) return VX_ERROR_INVALID_DIMENSION;
+    if (interp != VX_INTERPOLATION_BILINEAR && interp != VX_INTERPOLATION_NEAREST_NEIGHBOR) return VX_ERROR_NOT_SUPPORTED;
+    if (border.mode == VX_BORDER_REPLICATE) return VX_ERROR_NOT_SUPPORTED;
+    vx_status s = ensure_image(in);
+    if (s == VX_SUCCESS) s = ensure_image(out);
+    if (s != VX_SUCCESS) return s;
+    WarpPerspectiveParams p{};
+    p.src = view_of(in);
+    p.dst = out->dev; p.dst_pitch = out->pitch; p.dst_width = out->width; p.dst_height = out->height;
+    p.channels = in->bpp;
+    const float *d = reinterpret_cast<const float *>(mat->host.data());
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) p.m[3 * r + c] = d[3 * c + r];
+    p.bilinear = interp == VX_INTERPOLATION_BILINEAR;
+    p.border = 0;
+    if (border.mode == VX_BORDER_CONSTANT) {
+        if (in->bpp == 4) memcpy(&p.border, border.constant_value.RGBX, 4);
+        else p.border = border.constant_value.U8;
+    }
+    return hip_status(launch_warp_perspective(p, stream));
+}
+
+vx_status sync_host_view(_vx_graph *g);
+
 template <typename T>
 T *param(_vx_node *n, size_t i, vx_enum type) { return i < n->params.size() ? as<T>(n->params[i], type) : nullptr; }
 
@@ -677,6 +757,23 @@ vx_status run_node(_vx_node *n, hipStream_t stream)
                                   scalar_u32(n, 6), scalar_f32(n, 7), scalar_f32(n, 8), param<_vx_array>(n, 9, VX_TYPE_ARRAY),
                                   n->scratch, n->scratch_size, stream);
     }
+    case K_WARP_PERSPECTIVE: {
+        auto *m = param<_vx_matrix>(n, 1, VX_TYPE_MATRIX);
+        auto *t = param<_vx_scalar>(n, 2, VX_TYPE_SCALAR);
+        if (m && m->mirror_pending && n->graph) {   // written by a kernel of this run: its values reach the host at stream completion
+            vx_status s = sync_host_view(n->graph);
+            if (s != VX_SUCCESS) return s;
+        }
+        return do_warp_perspective(param<_vx_image>(n, 0, VX_TYPE_IMAGE), m, t ? t->v.e : 0, param<_vx_image>(n, 3, VX_TYPE_IMAGE),
+                                   n->border, stream);
+    }
+    case K_USER: {
+        if (!n->kernel || !n->kernel->func || !n->graph) return VX_ERROR_INVALID_NODE;
+        // host code: everything the earlier nodes produced must be complete and visible through the accessors
+        vx_status s = sync_host_view(n->graph);
+        if (s != VX_SUCCESS) return s;
+        return n->kernel->func(n, n->params.data(), (vx_uint32)n->params.size());
+    }
     case K_COLOR_CONVERT:
         return do_color_convert(param<_vx_image>(n, 0, VX_TYPE_IMAGE), param<_vx_image>(n, 1, VX_TYPE_IMAGE), stream);
     case K_COPY_IMAGE:
@@ -715,6 +812,9 @@ void keys_of(_vx_reference *r, std::vector<const void *> *out)
     } else if (r->type == VX_TYPE_IMAGE) {
         auto *im = static_cast<_vx_image *>(r);
         if (im->pyramid) out->push_back(im->pyramid);
+        for (_vx_image *p = im->parent; p; p = p->parent) out->push_back(p);     // a view stands for its parent too
+    } else if (r->type == VX_TYPE_DELAY) {                                        // a delay stands for all of its slots
+        for (auto *sl : static_cast<_vx_delay *>(r)->slots) keys_of(sl, out);
     }
 }
 
@@ -722,6 +822,72 @@ bool intersects(const std::vector<const void *> &a, const std::vector<const void
 {
     for (auto x : a) for (auto y : b) if (x == y) return true;
     return false;
+}
+
+// the attribute of whatever object `r` is, through the public query of its type
+vx_status query_any(_vx_reference *r, vx_enum attribute, void *ptr, vx_size size)
+{
+    switch (r->type) {
+    case VX_TYPE_IMAGE: return vxQueryImage(static_cast<_vx_image *>(r), attribute, ptr, size);
+    case VX_TYPE_ARRAY: return vxQueryArray(static_cast<_vx_array *>(r), attribute, ptr, size);
+    case VX_TYPE_MATRIX: return vxQueryMatrix(static_cast<_vx_matrix *>(r), attribute, ptr, size);
+    case VX_TYPE_SCALAR: return vxQueryScalar(static_cast<_vx_scalar *>(r), attribute, ptr, size);
+    case VX_TYPE_PYRAMID: return vxQueryPyramid(static_cast<_vx_pyramid *>(r), attribute, ptr, size);
+    case VX_TYPE_DELAY: return vxQueryDelay(static_cast<_vx_delay *>(r), attribute, ptr, size);
+    default: return VX_ERROR_NOT_SUPPORTED;
+    }
+}
+
+// a user node at vxVerifyGraph: the kernel's validator sees the parameters and describes every output in a meta
+// format (homography_filter_node.cpp:162-202); what it set must agree with the object bound to that output
+vx_status verify_user_node(_vx_node *nd)
+{
+    _vx_context *ctx = nd->ctx;
+    _vx_kernel *k = nd->kernel;
+    if (!k || !k->finalized) return VX_ERROR_INVALID_NODE;
+    const vx_uint32 num = (vx_uint32)nd->params.size();
+    std::vector<_vx_meta_format *> metas(num, nullptr);
+    for (auto &m : metas) {
+        m = new _vx_meta_format();
+        m->type = VX_TYPE_META_FORMAT;
+        m->ctx = ctx;
+    }
+    vx_status st = VX_SUCCESS;
+    if (k->validate) st = k->validate(nd, nd->params.data(), num, metas.data());
+    if (st != VX_SUCCESS) {
+        std::string msg = "vxVerifyGraph: the validator of user kernel '" + k->name + "' rejected its parameters";
+        log_msg(ctx, nd, st, msg.c_str());
+    }
+    for (vx_uint32 i = 0; i < num && st == VX_SUCCESS; ++i) {
+        _vx_reference *r = nd->params[i];
+        if (!r || nd->spec[i].dir == VX_INPUT) continue;
+        if (r->type == VX_TYPE_IMAGE) {    // a virtual image takes what the validator says
+            auto *im = static_cast<_vx_image *>(r);
+            auto w = metas[i]->attrs.find(VX_IMAGE_WIDTH), h = metas[i]->attrs.find(VX_IMAGE_HEIGHT);
+            if (im->is_virtual && im->width == 0 && im->height == 0 && !im->dev && w != metas[i]->attrs.end() &&
+                h != metas[i]->attrs.end() && w->second.size() == 4 && h->second.size() == 4) {
+                memcpy(&im->width, w->second.data(), 4);
+                memcpy(&im->height, h->second.data(), 4);
+            }
+        }
+        for (auto &kv : metas[i]->attrs) {
+            std::vector<uint8_t> have(kv.second.size());
+            if (query_any(r, kv.first, have.data(), have.size()) != VX_SUCCESS || have != kv.second) {
+                std::string msg = "vxVerifyGraph: an output of user kernel '" + k->name + "' does not match the validator's meta format";
+                log_msg(ctx, nd, VX_ERROR_INVALID_PARAMETERS, msg.c_str());
+                st = VX_ERROR_INVALID_PARAMETERS;
+                break;
+            }
+        }
+    }
+    for (auto *m : metas) { m->magic = 0; delete m; }
+    if (st != VX_SUCCESS) return st;
+    if (k->init && !nd->user_initialized) {
+        st = k->init(nd, nd->params.data(), num);
+        if (st != VX_SUCCESS) return st;
+    }
+    nd->user_initialized = true;
+    return VX_SUCCESS;
 }
 
 vx_status verify_graph(_vx_graph *g)
@@ -746,7 +912,10 @@ vx_status verify_graph(_vx_graph *g)
             if (sp.type == VX_TYPE_SCALAR) continue;
             if (sp.dir == VX_INPUT || sp.dir == VX_BIDIRECTIONAL) keys_of(r, &rd[i]);
             if (sp.dir == VX_OUTPUT || sp.dir == VX_BIDIRECTIONAL) {
-                if (nd->kind == K_COLOR_CONVERT || nd->kind == K_COPY_IMAGE) wr[i].push_back(r);   // the image only
+                if (nd->kind == K_COLOR_CONVERT || nd->kind == K_COPY_IMAGE) {   // the image only (not the pyramid it may be level 0 of)
+                    wr[i].push_back(r);
+                    for (_vx_image *pp = static_cast<_vx_image *>(r)->parent; pp; pp = pp->parent) wr[i].push_back(pp);
+                }
                 else keys_of(r, &wr[i]);
             }
         }
@@ -799,6 +968,27 @@ vx_status verify_graph(_vx_graph *g)
         }
     }
     // metadata checks that need no device
+    for (_vx_node *nd : g->order) {
+        if (nd->kind == K_USER) {
+            vx_status us = verify_user_node(nd);
+            if (us != VX_SUCCESS) return us;
+        }
+        if (nd->kind == K_WARP_PERSPECTIVE) {
+            auto *in = param<_vx_image>(nd, 0, VX_TYPE_IMAGE), *out = param<_vx_image>(nd, 3, VX_TYPE_IMAGE);
+            auto *m = param<_vx_matrix>(nd, 1, VX_TYPE_MATRIX);
+            auto *t = param<_vx_scalar>(nd, 2, VX_TYPE_SCALAR);
+            if (!in || !out || in->format != out->format) {
+                log_msg(ctx, nd, VX_ERROR_INVALID_FORMAT, "vxWarpPerspectiveNode: input and output must both be U8 or both RGBX");
+                return VX_ERROR_INVALID_FORMAT;
+            }
+            if (out->width == 0 || out->height == 0) return VX_ERROR_INVALID_DIMENSION;
+            if (!m || m->data_type != VX_TYPE_FLOAT32 || m->cols != 3 || m->rows != 3) return VX_ERROR_INVALID_DIMENSION;
+            if (!t || (t->v.e != VX_INTERPOLATION_BILINEAR && t->v.e != VX_INTERPOLATION_NEAREST_NEIGHBOR)) {
+                log_msg(ctx, nd, VX_ERROR_NOT_SUPPORTED, "vxWarpPerspectiveNode: NEAREST_NEIGHBOR and BILINEAR are offered");
+                return VX_ERROR_NOT_SUPPORTED;
+            }
+        }
+    }
     for (_vx_node *nd : g->nodes) {
         if (nd->kind == K_FIND_HOMOGRAPHY) {
             auto *a = param<_vx_array>(nd, 0, VX_TYPE_ARRAY), *b = param<_vx_array>(nd, 1, VX_TYPE_ARRAY);
@@ -838,7 +1028,7 @@ vx_status verify_graph(_vx_graph *g)
     g->matrices.clear();
     for (_vx_node *nd : g->order) {
         for (size_t p = 0; p < nd->params.size(); ++p)
-            if (nd->params[p] && nd->spec[p].type == VX_TYPE_MATRIX && nd->spec[p].dir != VX_INPUT) {
+            if (nd->kind != K_USER && nd->params[p] && nd->spec[p].type == VX_TYPE_MATRIX && nd->spec[p].dir != VX_INPUT) {
                 auto *m = static_cast<_vx_matrix *>(nd->params[p]);
                 if (std::find(g->matrices.begin(), g->matrices.end(), m) == g->matrices.end()) g->matrices.push_back(m);
             }
@@ -877,6 +1067,48 @@ void update_perf(vx_perf_t *p, uint64_t ns)
     p->max = ns > p->max ? ns : p->max;
 }
 
+// The pinned slots of a graph, in a fixed order: one per written array (its count), one per corner node with a
+// num_corners scalar, a few per written matrix.  The kernels that produce these values also store them there, so the
+// host has them at stream completion without a read-back copy.
+template <typename FA, typename FN, typename FM>
+void walk_mirrors(_vx_graph *g, FA on_array, FN on_node, FM on_matrix)
+{
+    size_t slot = 0;
+    for (_vx_array *a : g->written) { on_array(a, &g->pinned[slot]); slot += 2; }
+    for (_vx_node *n : g->corner_nodes) { on_node(n, reinterpret_cast<uint64_t *>(&g->pinned[slot])); slot += 2; }
+    for (_vx_matrix *m : g->matrices) { on_matrix(m, reinterpret_cast<float *>(&g->pinned[slot])); slot += 2 * ((m->host.size() + 7) / 8); }
+}
+
+// Drains the graph's stream and brings the host's view (array counts, num_corners scalars, matrix values) up to date
+// with what the kernels enqueued so far have written.  Called before every host (user-kernel) node and at the end.
+vx_status sync_host_view(_vx_graph *g)
+{
+    if (hipStreamSynchronize(g->stream) != hipSuccess) { g->state = VX_GRAPH_STATE_ABANDONED; return VX_FAILURE; }
+    walk_mirrors(g,
+        [](_vx_array *a, uint32_t *slot) {
+            if (!a->mirror_pending) return;
+            a->num_items = std::min<size_t>(*slot, a->capacity);
+            a->mirror_pending = false;
+        },
+        [](_vx_node *n, uint64_t *slot) {
+            if (!n->corners_pending) return;
+            n->corners_pending = false;
+            uint64_t v;
+            memcpy(&v, slot, 8);
+            if (auto *s = param<_vx_scalar>(n, 7, VX_TYPE_SCALAR)) {
+                if (s->data_type == VX_TYPE_SIZE) s->v.sz = (vx_size)v;
+                else if (s->data_type == VX_TYPE_UINT32) s->v.u32 = (vx_uint32)v;
+                else if (s->data_type == VX_TYPE_UINT64) s->v.u64 = v;
+            }
+        },
+        [](_vx_matrix *m, float *slot) {
+            if (!m->mirror_pending) return;
+            memcpy(m->host.data(), slot, m->host.size());
+            m->mirror_pending = false;
+        });
+    return VX_SUCCESS;
+}
+
 vx_status enqueue_graph(_vx_graph *g)
 {
     _vx_context *ctx = g->ctx;
@@ -887,31 +1119,50 @@ vx_status enqueue_graph(_vx_graph *g)
     }
     if (hipSetDevice(ctx->device) != hipSuccess) return VX_FAILURE;
     g->t0 = std::chrono::steady_clock::now();
-    // the kernels that write an array's count / a node's num_corners also store them to these pinned slots,
-    // so the host has them at stream completion without a read-back copy
-    size_t slot = 0;
-    for (_vx_array *a : g->written) { a->count_mirror = &g->pinned[slot]; slot += 2; }
-    for (_vx_node *n : g->corner_nodes) { n->num_corners_mirror = reinterpret_cast<uint64_t *>(&g->pinned[slot]); slot += 2; }
-    for (_vx_matrix *m : g->matrices) { m->mirror = reinterpret_cast<float *>(&g->pinned[slot]); slot += 2 * ((m->host.size() + 7) / 8); }
+    walk_mirrors(g, [](_vx_array *a, uint32_t *slot) { a->count_mirror = slot; a->mirror_pending = false; },
+                 [](_vx_node *n, uint64_t *slot) { n->num_corners_mirror = slot; n->corners_pending = false; },
+                 [](_vx_matrix *m, float *slot) { m->mirror = slot; m->mirror_pending = false; });
+    vx_status result = VX_SUCCESS;
     for (_vx_node *n : g->order) {
         n->timed = ctx->perf || g->perf_enabled || n->perf_enabled;
-        if (n->timed) {
-            if (!n->ev0 && (hipEventCreate(&n->ev0) != hipSuccess || hipEventCreate(&n->ev1) != hipSuccess)) return VX_FAILURE;
+        const bool host_node = n->kind == K_USER;
+        std::chrono::steady_clock::time_point h0;
+        if (n->timed && !host_node) {
+            if (!n->ev0 && (hipEventCreate(&n->ev0) != hipSuccess || hipEventCreate(&n->ev1) != hipSuccess)) { result = VX_FAILURE; break; }
             (void)hipEventRecord(n->ev0, g->stream);
         }
+        if (host_node) h0 = std::chrono::steady_clock::now();
         n->last_status = run_node(n, g->stream);
-        if (n->timed) (void)hipEventRecord(n->ev1, g->stream);
+        if (host_node) {
+            // a host node is timed on the host clock (its wait for the stream to drain excluded would need a second
+            // clock read inside run_node; the callbacks here are microseconds of matrix arithmetic)
+            if (n->timed) update_perf(&n->perf, (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h0).count());
+        } else {
+            if (n->timed) (void)hipEventRecord(n->ev1, g->stream);
+            // what this kernel stores to the pinned slots is valid once the stream has passed it
+            for (size_t p = 0; p < n->params.size(); ++p) {
+                _vx_reference *r = n->params[p];
+                if (!r || n->spec[p].dir == VX_INPUT) continue;
+                if (r->type == VX_TYPE_ARRAY) static_cast<_vx_array *>(r)->mirror_pending = true;
+                else if (r->type == VX_TYPE_MATRIX) static_cast<_vx_matrix *>(r)->mirror_pending = true;
+            }
+            if ((n->kind == K_HARRIS_TRACK || n->kind == K_FAST_TRACK) && param<_vx_scalar>(n, 7, VX_TYPE_SCALAR)) n->corners_pending = true;
+        }
         if (n->last_status != VX_SUCCESS) {
             char msg[160];
             snprintf(msg, sizeof(msg), "node %d of the graph failed with status %d", (int)n->kind, (int)n->last_status);
             log_msg(ctx, n, n->last_status, msg);
-            (void)hipStreamSynchronize(g->stream);
-            g->state = VX_GRAPH_STATE_ABANDONED;
-            return n->last_status;
+            result = n->last_status;
+            break;
         }
     }
-    for (_vx_array *a : g->written) a->count_mirror = nullptr;
-    for (_vx_matrix *m : g->matrices) m->mirror = nullptr;
+    walk_mirrors(g, [](_vx_array *a, uint32_t *) { a->count_mirror = nullptr; }, [](_vx_node *n, uint64_t *) { n->num_corners_mirror = nullptr; },
+                 [](_vx_matrix *m, float *) { m->mirror = nullptr; });
+    if (result != VX_SUCCESS) {
+        (void)sync_host_view(g);
+        g->state = VX_GRAPH_STATE_ABANDONED;
+        return result;
+    }
     g->scheduled = true;
     g->state = VX_GRAPH_STATE_RUNNING;
     return VX_SUCCESS;
@@ -920,26 +1171,11 @@ vx_status enqueue_graph(_vx_graph *g)
 vx_status finish_graph(_vx_graph *g)
 {
     if (!g->scheduled) return VX_FAILURE;
-    if (hipStreamSynchronize(g->stream) != hipSuccess) { g->state = VX_GRAPH_STATE_ABANDONED; return VX_FAILURE; }
     g->scheduled = false;
-    size_t slot = 0;
-    for (_vx_array *a : g->written) { a->num_items = std::min<size_t>(g->pinned[slot], a->capacity); slot += 2; }
-    for (_vx_node *n : g->corner_nodes) {
-        uint64_t v;
-        memcpy(&v, &g->pinned[slot], 8);
-        slot += 2;
-        if (auto *s = param<_vx_scalar>(n, 7, VX_TYPE_SCALAR)) {
-            if (s->data_type == VX_TYPE_SIZE) s->v.sz = (vx_size)v;
-            else if (s->data_type == VX_TYPE_UINT32) s->v.u32 = (vx_uint32)v;
-            else if (s->data_type == VX_TYPE_UINT64) s->v.u64 = v;
-        }
-    }
-    for (_vx_matrix *m : g->matrices) {
-        memcpy(m->host.data(), &g->pinned[slot], m->host.size());
-        slot += 2 * ((m->host.size() + 7) / 8);
-    }
+    vx_status s = sync_host_view(g);
+    if (s != VX_SUCCESS) return s;
     for (_vx_node *n : g->order)
-        if (n->timed) {
+        if (n->timed && n->kind != K_USER) {
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, n->ev0, n->ev1) == hipSuccess) update_perf(&n->perf, (uint64_t)(ms * 1e6));
         }
@@ -950,7 +1186,8 @@ vx_status finish_graph(_vx_graph *g)
 }
 
 // ---- node construction -------------------------------------------------------------------------
-vx_node make_node(vx_graph graph, KernelKind kind, std::vector<ParamSpec> spec, std::vector<_vx_reference *> params)
+vx_node make_node(vx_graph graph, KernelKind kind, std::vector<ParamSpec> spec, std::vector<_vx_reference *> params,
+                  bool allow_unset = false)
 {
     auto *g = as<_vx_graph>(graph, VX_TYPE_GRAPH);
     if (!g) return nullptr;
@@ -958,7 +1195,7 @@ vx_node make_node(vx_graph graph, KernelKind kind, std::vector<ParamSpec> spec, 
     for (size_t i = 0; i < params.size(); ++i) {
         _vx_reference *r = params[i];
         if (!r) {
-            if (!spec[i].optional) return make_error<vx_node>(ctx, VX_ERROR_INVALID_PARAMETERS, "node creation: a required parameter is NULL");
+            if (!spec[i].optional && !allow_unset) return make_error<vx_node>(ctx, VX_ERROR_INVALID_PARAMETERS, "node creation: a required parameter is NULL");
             continue;
         }
         if (!valid(r, spec[i].type)) return make_error<vx_node>(ctx, VX_ERROR_INVALID_REFERENCE, "node creation: a parameter has the wrong type");
@@ -1086,12 +1323,17 @@ vx_status vxReleaseContext(vx_context *context)
     *context = nullptr;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     // tear down whatever the application left behind: graphs first, then containers, then leaves
-    static const vx_enum order[] = { VX_TYPE_GRAPH, VX_TYPE_NODE, VX_TYPE_DELAY, VX_TYPE_PYRAMID, VX_TYPE_IMAGE,
+    ctx->kernels.clear();
+    static const vx_enum order[] = { VX_TYPE_GRAPH, VX_TYPE_NODE, VX_TYPE_KERNEL, VX_TYPE_DELAY, VX_TYPE_PYRAMID, VX_TYPE_IMAGE,
                                      VX_TYPE_ARRAY, VX_TYPE_MATRIX, VX_TYPE_SCALAR };
     for (vx_enum t : order) {
         for (;;) {
             _vx_reference *victim = nullptr;
-            for (auto *r : ctx->live) if (r->type == t) { victim = r; break; }
+            // views before the images they look into
+            if (t == VX_TYPE_IMAGE)
+                for (auto *r : ctx->live) if (r->type == t && static_cast<_vx_image *>(r)->parent) { victim = r; break; }
+            if (!victim)
+                for (auto *r : ctx->live) if (r->type == t) { victim = r; break; }
             if (!victim) break;
             victim->refs = 0;
             destroy(victim);
@@ -1203,6 +1445,41 @@ vx_image vxCreateImage(vx_context context, vx_uint32 width, vx_uint32 height, vx
 }
 
 vx_status vxReleaseImage(vx_image *image) { return release_handle(image, VX_TYPE_IMAGE); }
+
+vx_image vxCreateUniformImage(vx_context context, vx_uint32 width, vx_uint32 height, vx_df_image color, const vx_pixel_value_t *value)
+{
+    vx_image im = vxCreateImage(context, width, height, color);
+    if (!valid(im, VX_TYPE_IMAGE)) return im;
+    if (!value) { release_ref(im); return make_error<vx_image>(context, VX_ERROR_INVALID_PARAMETERS, "vxCreateUniformImage: no value"); }
+    im->has_fill = true;
+    if (color == VX_DF_IMAGE_RGBX) memcpy(&im->fill, value->RGBX, 4);
+    else im->fill = value->U8;
+    return im;
+}
+
+vx_image vxCreateImageFromROI(vx_image img, const vx_rectangle_t *rect)
+{
+    auto *parent = as<_vx_image>(img, VX_TYPE_IMAGE);
+    if (!parent) return nullptr;
+    _vx_context *ctx = parent->ctx;
+    if (!rect || rect->start_x >= rect->end_x || rect->start_y >= rect->end_y || rect->end_x > parent->width || rect->end_y > parent->height)
+        return make_error<vx_image>(ctx, VX_ERROR_INVALID_PARAMETERS, "vxCreateImageFromROI: the rectangle must lie inside the image");
+    _vx_image *v = new_image(ctx, rect->end_x - rect->start_x, rect->end_y - rect->start_y, parent->format);
+    v->parent = parent;
+    v->roi_x = rect->start_x;
+    v->roi_y = rect->start_y;
+    retain(parent);
+    return v;
+}
+
+vx_status vxGetValidRegionImage(vx_image image, vx_rectangle_t *rect)
+{
+    auto *im = as<_vx_image>(image, VX_TYPE_IMAGE);
+    if (!im) return VX_ERROR_INVALID_REFERENCE;
+    if (!rect) return VX_ERROR_INVALID_PARAMETERS;
+    rect->start_x = 0; rect->start_y = 0; rect->end_x = im->width; rect->end_y = im->height;
+    return VX_SUCCESS;
+}
 
 vx_status vxQueryImage(vx_image image, vx_enum attribute, void *ptr, vx_size size)
 {
@@ -1552,6 +1829,13 @@ vx_delay vxCreateDelay(vx_context context, vx_reference exemplar, vx_size num_sl
         case VX_TYPE_PYRAMID: { auto *e = static_cast<_vx_pyramid *>(exemplar); s = new_pyramid(context, e->levels.size(), e->scale, e->width, e->height, e->format); break; }
         case VX_TYPE_ARRAY: { auto *e = static_cast<_vx_array *>(exemplar); s = new_array(context, e->item_type, e->capacity); break; }
         case VX_TYPE_SCALAR: { auto *e = static_cast<_vx_scalar *>(exemplar); s = new_scalar(context, e->data_type, &e->v); break; }
+        case VX_TYPE_MATRIX: {   // demos/video_stabilizer/stabilizer.cpp:438
+            auto *e = static_cast<_vx_matrix *>(exemplar);
+            _vx_matrix *m = new_matrix(context, e->data_type, e->cols, e->rows);
+            m->host = e->host;
+            s = m;
+            break;
+        }
         default: break;
         }
         if (!s) {
@@ -1613,6 +1897,11 @@ vx_status vxAgeDelay(vx_delay delay)
             break;
         }
         case VX_TYPE_SCALAR: std::swap(static_cast<_vx_scalar *>(older)->v, static_cast<_vx_scalar *>(newer)->v); break;
+        case VX_TYPE_MATRIX: {
+            auto *mo = static_cast<_vx_matrix *>(older), *mn = static_cast<_vx_matrix *>(newer);
+            std::swap(mo->host, mn->host); std::swap(mo->dev, mn->dev);
+            break;
+        }
         default: return VX_ERROR_NOT_SUPPORTED;
         }
     }
@@ -1702,7 +1991,12 @@ vx_status vxQueryNode(vx_node node, vx_enum attribute, void *ptr, vx_size size)
     case VX_NODE_PERFORMANCE: return query_out(ptr, size, &n->perf, sizeof(vx_perf_t));
     case VX_NODE_STATUS: return query_out(ptr, size, &n->last_status, sizeof(vx_status));
     case VX_NODE_PARAMETERS: { vx_uint32 v = (vx_uint32)n->params.size(); return query_out(ptr, size, &v, sizeof(v)); }
-    case VX_NODE_BORDER: { vx_border_t b{}; b.mode = VX_BORDER_REPLICATE; return query_out(ptr, size, &b, sizeof(b)); }
+    case VX_NODE_BORDER: {
+        vx_border_t b{};
+        b.mode = VX_BORDER_REPLICATE;
+        if (n->kind == K_WARP_PERSPECTIVE) { b = n->border; if (b.mode == VX_BORDER_UNDEFINED) b.mode = VX_BORDER_CONSTANT; }
+        return query_out(ptr, size, &b, sizeof(b));
+    }
     default: return VX_ERROR_NOT_SUPPORTED;
     }
 }
@@ -1714,7 +2008,14 @@ vx_status vxSetNodeAttribute(vx_node node, vx_enum attribute, const void *ptr, v
     if (attribute == VX_NODE_BORDER) {
         // UNDEFINED is refined to REPLICATE and REPLICATE is what the kernels do; CONSTANT is not offered
         if (!ptr || size != sizeof(vx_border_t)) return VX_ERROR_INVALID_PARAMETERS;
-        return static_cast<const vx_border_t *>(ptr)->mode == VX_BORDER_CONSTANT ? VX_ERROR_NOT_SUPPORTED : VX_SUCCESS;
+        const vx_border_t *b = static_cast<const vx_border_t *>(ptr);
+        if (n->kind == K_WARP_PERSPECTIVE) {   // samples outside the input: a constant (UNDEFINED is refined to constant 0)
+            if (b->mode == VX_BORDER_REPLICATE) return VX_ERROR_NOT_SUPPORTED;
+            n->border = *b;
+            if (b->mode == VX_BORDER_UNDEFINED) memset(&n->border.constant_value, 0, sizeof(n->border.constant_value));
+            return VX_SUCCESS;
+        }
+        return b->mode == VX_BORDER_CONSTANT ? VX_ERROR_NOT_SUPPORTED : VX_SUCCESS;
     }
     return VX_ERROR_NOT_SUPPORTED;
 }
@@ -1747,6 +2048,182 @@ vx_status vxSetParameterByIndex(vx_node node, vx_uint32 index, vx_reference valu
     release_ref(old);
     if (!same_meta && n->graph) { n->graph->verified = false; n->graph->state = VX_GRAPH_STATE_UNVERIFIED; }
     return VX_SUCCESS;
+}
+
+// ---- user kernels ------------------------------------------------------------------------------
+vx_status vxAllocateUserKernelId(vx_context context, vx_enum *pKernelEnumId)
+{
+    if (!usable(context)) return VX_ERROR_INVALID_REFERENCE;
+    if (!pKernelEnumId) return VX_ERROR_INVALID_PARAMETERS;
+    std::lock_guard<std::recursive_mutex> lk(context->mu);
+    if (context->next_kernel_id >= VX_KERNEL_BASE(VX_ID_DEFAULT, 0) + 0x1000) return VX_ERROR_NO_RESOURCES;
+    *pKernelEnumId = context->next_kernel_id++;
+    return VX_SUCCESS;
+}
+
+vx_kernel vxAddUserKernel(vx_context context, const vx_char name[VX_MAX_KERNEL_NAME], vx_enum enumeration, vx_kernel_f func_ptr,
+                          vx_uint32 numParams, vx_kernel_validate_f validate, vx_kernel_initialize_f init,
+                          vx_kernel_deinitialize_f deinit)
+{
+    if (!valid(context) || context->type != VX_TYPE_CONTEXT) return nullptr;
+    if (context->status != VX_SUCCESS) return make_error<vx_kernel>(context, context->status);
+    if (!name || !name[0] || strnlen(name, VX_MAX_KERNEL_NAME) == VX_MAX_KERNEL_NAME || !func_ptr || numParams == 0 || numParams > 32)
+        return make_error<vx_kernel>(context, VX_ERROR_INVALID_PARAMETERS, "vxAddUserKernel: a name, a function and 1..32 parameters are required");
+    {
+        std::lock_guard<std::recursive_mutex> lk(context->mu);
+        if (context->kernels.count(name)) return make_error<vx_kernel>(context, VX_ERROR_INVALID_PARAMETERS, "vxAddUserKernel: the name is taken");
+    }
+    auto *k = new _vx_kernel();
+    k->type = VX_TYPE_KERNEL;
+    k->ctx = context;
+    k->name = name;
+    k->enumeration = enumeration;
+    k->func = func_ptr; k->validate = validate; k->init = init; k->deinit = deinit;
+    k->spec.assign(numParams, ParamSpec{ VX_INPUT, VX_TYPE_INVALID, false });
+    k->spec_set.assign(numParams, false);
+    track(context, k);
+    return k;
+}
+
+vx_status vxAddParameterToKernel(vx_kernel kernel, vx_uint32 index, vx_enum dir, vx_enum data_type, vx_enum state)
+{
+    auto *k = as<_vx_kernel>(kernel, VX_TYPE_KERNEL);
+    if (!k) return VX_ERROR_INVALID_REFERENCE;
+    if (k->finalized) return VX_ERROR_NOT_SUPPORTED;
+    if (index >= k->spec.size() || (dir != VX_INPUT && dir != VX_OUTPUT && dir != VX_BIDIRECTIONAL) ||
+        (state != VX_PARAMETER_STATE_REQUIRED && state != VX_PARAMETER_STATE_OPTIONAL))
+        return VX_ERROR_INVALID_PARAMETERS;
+    switch (data_type) {
+    case VX_TYPE_IMAGE: case VX_TYPE_ARRAY: case VX_TYPE_MATRIX: case VX_TYPE_SCALAR: case VX_TYPE_PYRAMID: case VX_TYPE_DELAY: break;
+    default: return VX_ERROR_NOT_SUPPORTED;
+    }
+    k->spec[index] = ParamSpec{ dir, data_type, state == VX_PARAMETER_STATE_OPTIONAL };
+    k->spec_set[index] = true;
+    return VX_SUCCESS;
+}
+
+vx_status vxFinalizeKernel(vx_kernel kernel)
+{
+    auto *k = as<_vx_kernel>(kernel, VX_TYPE_KERNEL);
+    if (!k) return VX_ERROR_INVALID_REFERENCE;
+    if (k->finalized) return VX_SUCCESS;
+    for (bool set : k->spec_set) if (!set) return VX_ERROR_INVALID_PARAMETERS;
+    std::lock_guard<std::recursive_mutex> lk(k->ctx->mu);
+    if (k->ctx->kernels.count(k->name)) return VX_ERROR_INVALID_PARAMETERS;
+    k->finalized = true;
+    retain(k);                         // the registry's reference
+    k->ctx->kernels[k->name] = k;
+    return VX_SUCCESS;
+}
+
+vx_status vxRemoveKernel(vx_kernel kernel)
+{
+    auto *k = as<_vx_kernel>(kernel, VX_TYPE_KERNEL);
+    if (!k) return VX_ERROR_INVALID_REFERENCE;
+    {
+        std::lock_guard<std::recursive_mutex> lk(k->ctx->mu);
+        auto it = k->ctx->kernels.find(k->name);
+        if (it != k->ctx->kernels.end() && it->second == k) {
+            k->ctx->kernels.erase(it);
+            release_ref(k);            // the registry's
+        }
+    }
+    release_ref(k);                    // the caller's
+    return VX_SUCCESS;
+}
+
+vx_status vxReleaseKernel(vx_kernel *kernel) { return release_handle(kernel, VX_TYPE_KERNEL); }
+
+vx_status vxQueryKernel(vx_kernel kernel, vx_enum attribute, void *ptr, vx_size size)
+{
+    auto *k = as<_vx_kernel>(kernel, VX_TYPE_KERNEL);
+    if (!k) return VX_ERROR_INVALID_REFERENCE;
+    switch (attribute) {
+    case VX_KERNEL_PARAMETERS: { vx_uint32 v = (vx_uint32)k->spec.size(); return query_out(ptr, size, &v, sizeof(v)); }
+    case VX_KERNEL_ENUM: return query_out(ptr, size, &k->enumeration, sizeof(vx_enum));
+    case VX_KERNEL_NAME: {
+        if (!ptr || size != VX_MAX_KERNEL_NAME) return VX_ERROR_INVALID_PARAMETERS;
+        memset(ptr, 0, size);
+        memcpy(ptr, k->name.data(), k->name.size());
+        return VX_SUCCESS;
+    }
+    default: return VX_ERROR_NOT_SUPPORTED;
+    }
+}
+
+vx_kernel vxGetKernelByName(vx_context context, const vx_char *name)
+{
+    if (!valid(context) || context->type != VX_TYPE_CONTEXT) return nullptr;
+    if (context->status != VX_SUCCESS) return make_error<vx_kernel>(context, context->status);
+    std::lock_guard<std::recursive_mutex> lk(context->mu);
+    auto it = name ? context->kernels.find(name) : context->kernels.end();
+    if (it == context->kernels.end()) return make_error<vx_kernel>(context, VX_ERROR_INVALID_PARAMETERS, "vxGetKernelByName: no such kernel");
+    retain(it->second);
+    return it->second;
+}
+
+vx_kernel vxGetKernelByEnum(vx_context context, vx_enum kernel)
+{
+    if (!valid(context) || context->type != VX_TYPE_CONTEXT) return nullptr;
+    if (context->status != VX_SUCCESS) return make_error<vx_kernel>(context, context->status);
+    std::lock_guard<std::recursive_mutex> lk(context->mu);
+    for (auto &kv : context->kernels)
+        if (kv.second->enumeration == kernel) { retain(kv.second); return kv.second; }
+    return make_error<vx_kernel>(context, VX_ERROR_INVALID_PARAMETERS, "vxGetKernelByEnum: no such kernel");
+}
+
+vx_node vxCreateGenericNode(vx_graph graph, vx_kernel kernel)
+{
+    auto *g = as<_vx_graph>(graph, VX_TYPE_GRAPH);
+    if (!g) return nullptr;
+    auto *k = as<_vx_kernel>(kernel, VX_TYPE_KERNEL);
+    if (!k || !k->finalized || k->ctx != g->ctx) return make_error<vx_node>(g->ctx, VX_ERROR_INVALID_REFERENCE, "vxCreateGenericNode: not a finalized kernel of this context");
+    vx_node n = make_node(graph, K_USER, k->spec, std::vector<_vx_reference *>(k->spec.size(), nullptr), true);
+    if (valid(n, VX_TYPE_NODE)) {
+        n->kernel = k;
+        retain(k);
+    }
+    return n;
+}
+
+vx_status vxSetMetaFormatAttribute(vx_meta_format meta, vx_enum attribute, const void *ptr, vx_size size)
+{
+    if (!valid(meta) || meta->type != VX_TYPE_META_FORMAT) return VX_ERROR_INVALID_REFERENCE;
+    if (!ptr || size == 0 || size > 64) return VX_ERROR_INVALID_PARAMETERS;
+    const uint8_t *b = static_cast<const uint8_t *>(ptr);
+    meta->attrs[attribute].assign(b, b + size);
+    return VX_SUCCESS;
+}
+
+vx_status vxSetMetaFormatFromReference(vx_meta_format meta, vx_reference exemplar)
+{
+    if (!valid(meta) || meta->type != VX_TYPE_META_FORMAT || !valid(exemplar)) return VX_ERROR_INVALID_REFERENCE;
+    auto put = [&](vx_enum attr, size_t n) {
+        std::vector<uint8_t> v(n);
+        if (query_any(exemplar, attr, v.data(), n) == VX_SUCCESS) meta->attrs[attr] = v;
+    };
+    switch (exemplar->type) {
+    case VX_TYPE_IMAGE: put(VX_IMAGE_WIDTH, 4); put(VX_IMAGE_HEIGHT, 4); put(VX_IMAGE_FORMAT, 4); break;
+    case VX_TYPE_ARRAY: put(VX_ARRAY_ITEMTYPE, 4); put(VX_ARRAY_CAPACITY, sizeof(vx_size)); break;
+    case VX_TYPE_MATRIX: put(VX_MATRIX_TYPE, 4); put(VX_MATRIX_ROWS, sizeof(vx_size)); put(VX_MATRIX_COLUMNS, sizeof(vx_size)); break;
+    case VX_TYPE_SCALAR: put(VX_SCALAR_TYPE, 4); break;
+    default: return VX_ERROR_NOT_SUPPORTED;
+    }
+    return VX_SUCCESS;
+}
+
+vx_node vxWarpPerspectiveNode(vx_graph graph, vx_image input, vx_matrix matrix, vx_enum type, vx_image output)
+{
+    auto *g = as<_vx_graph>(graph, VX_TYPE_GRAPH);
+    if (!g) return nullptr;
+    _vx_scalar *t = new_scalar(g->ctx, VX_TYPE_ENUM, &type);
+    vx_node n = make_node(graph, K_WARP_PERSPECTIVE,
+                          { { VX_INPUT, VX_TYPE_IMAGE, false }, { VX_INPUT, VX_TYPE_MATRIX, false }, { VX_INPUT, VX_TYPE_SCALAR, false },
+                            { VX_OUTPUT, VX_TYPE_IMAGE, false } },
+                          { R(input), R(matrix), t, R(output) });
+    release_ref(t);
+    if (valid(n, VX_TYPE_NODE)) n->border.mode = VX_BORDER_UNDEFINED;
+    return n;
 }
 
 vx_node vxColorConvertNode(vx_graph graph, vx_image input, vx_image output)
@@ -1925,6 +2402,17 @@ vx_status nvxuFindHomography(vx_context context, vx_array srcPoints, vx_array ds
     if (hipMemcpyAsync(m->host.data(), m->dev, m->host.size(), hipMemcpyDeviceToHost, context->stream) != hipSuccess) return VX_FAILURE;
     if (k) return refresh_count_now(k, context->stream);
     return hip_status(hipStreamSynchronize(context->stream));
+}
+
+vx_status vxuWarpPerspective(vx_context context, vx_image input, vx_matrix matrix, vx_enum type, vx_image output)
+{
+    vx_status s = immediate_begin(context);
+    if (s != VX_SUCCESS) return s;
+    vx_border_t b{};
+    b.mode = VX_BORDER_UNDEFINED;
+    s = do_warp_perspective(as<_vx_image>(input, VX_TYPE_IMAGE), as<_vx_matrix>(matrix, VX_TYPE_MATRIX), type,
+                            as<_vx_image>(output, VX_TYPE_IMAGE), b, context->stream);
+    return s == VX_SUCCESS ? hip_status(hipStreamSynchronize(context->stream)) : s;
 }
 
 vx_status nvxuCopyImage(vx_context context, vx_image src, vx_image dst)

@@ -38,7 +38,17 @@ VX_MEMORY_TYPE_HOST, NVX_MEMORY_TYPE_HIP = 0x0E001, 0x0E100
 VX_TERM_CRITERIA_ITERATIONS, VX_TERM_CRITERIA_EPSILON, VX_TERM_CRITERIA_BOTH = 0x17000, 0x17001, 0x17002
 NVX_GRAPH_VERIFY_OPTIONS = 0x80280
 VX_SCALE_PYRAMID_HALF = 0.5
-K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE, K_FIND_HOMOGRAPHY = range(7)
+K_COLOR_CONVERT, K_GAUSSIAN_PYRAMID, K_PYRLK, K_HARRIS_TRACK, K_FAST_TRACK, K_COPY_IMAGE, K_FIND_HOMOGRAPHY, \
+    K_WARP_PERSPECTIVE, K_USER = range(9)
+VX_TYPE_KERNEL, VX_TYPE_DELAY, VX_TYPE_SCALAR, VX_TYPE_NODE = 0x804, 0x806, 0x80D, 0x803
+VX_INPUT, VX_OUTPUT, VX_BIDIRECTIONAL = 0x04000, 0x04001, 0x04002
+VX_PARAMETER_STATE_REQUIRED, VX_PARAMETER_STATE_OPTIONAL = 0x06000, 0x06001
+VX_INTERPOLATION_NEAREST_NEIGHBOR, VX_INTERPOLATION_BILINEAR, VX_INTERPOLATION_AREA = 0x14000, 0x14001, 0x14002
+VX_BORDER_UNDEFINED, VX_BORDER_CONSTANT, VX_BORDER_REPLICATE = 0x0C000, 0x0C001, 0x0C002
+VX_NODE_BORDER = 0x80302
+VX_SCALAR_TYPE = 0x80D00
+VX_KERNEL_PARAMETERS, VX_KERNEL_NAME, VX_KERNEL_ENUM = 0x80400, 0x80401, 0x80402
+VX_ERROR_INVALID_NODE = -19
 VX_MATRIX_TYPE, VX_MATRIX_ROWS, VX_MATRIX_COLUMNS, VX_MATRIX_SIZE = 0x80B00, 0x80B01, 0x80B02, 0x80B03
 NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, NVX_FIND_HOMOGRAPHY_METHOD_LMEDS = 0x80300, 0x80301
 
@@ -56,7 +66,18 @@ class vx_imagepatch_addressing_t(C.Structure):
                 ("scale_x", C.c_uint32), ("scale_y", C.c_uint32), ("step_x", C.c_uint32), ("step_y", C.c_uint32)]
 
 
+class vx_border_t(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("constant_value", C.c_uint8 * 4)]
+
+
+class vx_pixel_value_t(C.Union):
+    _fields_ = [("RGBX", C.c_uint8 * 4), ("U8", C.c_uint8), ("U32", C.c_uint32), ("reserved", C.c_uint8 * 16)]
+
+
 LOG_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32, C.c_char_p)
+# user-kernel callbacks (VX/vx.h): func / init / deinit (node, parameters, num); validate (node, parameters, num, metas)
+KERNEL_F = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32)
+VALIDATE_F = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p))
 
 _SIGS = {
     "vxCreateContext": (C.c_void_p, []),
@@ -136,6 +157,24 @@ _SIGS = {
     "nvxFindHomographyNode": (C.c_void_p, [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
     "nvxuFindHomography": (C.c_int32, [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
     "visualslam_amd_graph_order": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    "vxSetNodeAttribute": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxCreateUniformImage": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "vxCreateImageFromROI": (C.c_void_p, [C.c_void_p, C.POINTER(vx_rectangle_t)]),
+    "vxGetValidRegionImage": (C.c_int32, [C.c_void_p, C.POINTER(vx_rectangle_t)]),
+    "vxWarpPerspectiveNode": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "vxuWarpPerspective": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "vxAllocateUserKernelId": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "vxAddUserKernel": (C.c_void_p, [C.c_void_p, C.c_char_p, C.c_int32, KERNEL_F, C.c_uint32, VALIDATE_F, KERNEL_F, KERNEL_F]),
+    "vxAddParameterToKernel": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32]),
+    "vxFinalizeKernel": (C.c_int32, [C.c_void_p]),
+    "vxRemoveKernel": (C.c_int32, [C.c_void_p]),
+    "vxReleaseKernel": (C.c_int32, [C.POINTER(C.c_void_p)]),
+    "vxQueryKernel": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxGetKernelByName": (C.c_void_p, [C.c_void_p, C.c_char_p]),
+    "vxGetKernelByEnum": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "vxCreateGenericNode": (C.c_void_p, [C.c_void_p, C.c_void_p]),
+    "vxSetMetaFormatAttribute": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxSetMetaFormatFromReference": (C.c_int32, [C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
