@@ -203,7 +203,9 @@ nvxcu_tmp_buf_size_t nvxcuOpticalFlowPyrLK_GetBufSize(uint32_t width, uint32_t h
                                                       const hipDeviceProp_t *dev_prop);
 /* replaces nvxcuOpticalFlowPyrLK -- feature_tracker_nvxcu.cpp:297-301, object_tracker_keypoint_nvxcu.cpp:1791-1828.
  * new_points holds the initial estimates on entry (count + payload, feature_tracker_nvxcu.cpp:288-295)
- * and the tracked positions on return; item count and order equal old_points'. */
+ * and the tracked positions on return; item count and order equal old_points'.  calc_error != 0 fills
+ * nvxcu_keypointf_t::error of tracked items with the mean absolute template difference at the final position
+ * (0 otherwise, and for lost items). */
 nvxcu_error_status_e nvxcuOpticalFlowPyrLK(const nvxcu_pyramid_t *old_pyramid, const nvxcu_pyramid_t *new_pyramid,
                                            const nvxcu_array_t *old_points, const nvxcu_array_t *new_points,
                                            nvxcu_term_criteria_e termination, float epsilon,

@@ -56,7 +56,7 @@ def lib(omp=False):
                                      u32, u32, u32, C.c_void_p, u32, C.POINTER(C.c_size_t), C.c_void_p]
         L.orc_fast_track.restype = u32
         L.orc_optical_flow_pyr_lk.argtypes = [C.POINTER(_Image), C.POINTER(_Image), u32, C.c_int,
-                                              C.c_void_p, C.c_void_p, u32, C.c_int, f32, u32, u32, C.c_int]
+                                              C.c_void_p, C.c_void_p, u32, C.c_int, f32, u32, u32, C.c_int, C.c_int]
         _libs[name] = L
     return _libs[name]
 
@@ -171,7 +171,7 @@ def _levels(pyr):
 
 def optical_flow_pyr_lk(prev_pyr, curr_pyr, prev_pts, estimates=None, termination=TERM_BOTH,
                         epsilon=0.01, num_iterations=5, window=10, item_type=POINT2F,
-                        sum_mode=SUM_WAVE64, omp=False):
+                        sum_mode=SUM_WAVE64, omp=False, calc_error=False):
     kp, ap = _levels(prev_pyr)
     kc, ac = _levels(curr_pyr)
     assert len(kp) == len(kc)
@@ -181,7 +181,7 @@ def optical_flow_pyr_lk(prev_pyr, curr_pyr, prev_pts, estimates=None, terminatio
     assert out.dtype == prev_pts.dtype and len(out) == len(prev_pts)
     lib(omp).orc_optical_flow_pyr_lk(ap, ac, len(kp), item_type, prev_pts.ctypes.data,
                                      out.ctypes.data, len(prev_pts), termination, epsilon,
-                                     num_iterations, window, sum_mode)
+                                     num_iterations, window, sum_mode, 1 if calc_error else 0)
     return out
 
 

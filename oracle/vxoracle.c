@@ -383,6 +383,9 @@ uint32_t orc_fast_track(const uint8_t *img, uint32_t pitch, uint32_t w, uint32_t
  *     position leaves [0,w-1]x[0,h-1] is lost; inputs already lost stay lost;
  *     |eta| < eps is tested as eta.x^2 + eta.y^2 < eps^2; EPSILON-only termination is capped at
  *     100 iterations.
+ *     calcError (thin layer, object_tracker_keypoint_nvxcu.cpp:1799,1824 pass 0): when set, a tracked KEYPOINTF item's
+ *     `error` is the mean absolute difference between the level-0 template and the new image sampled at the final
+ *     position, sum(|I - J|) / win^2 (same sampling, same summation order); 0 for lost points and when not requested.
  * Summation order (ORC_SUM_WAVE64, canonical): window pixels are dealt to 64 accumulators
  * (row = l / segs, segment = l % segs, seglen consecutive pixels each, ascending x), each
  * accumulating by fmaf in order, then combined by a pairwise butterfly (offsets 1,2,4,..,32).
@@ -430,7 +433,7 @@ static inline float bilerp(float a, float b, float c, float d, float fx, float f
 static int lk_track_one(const orc_image_t *prev, const orc_image_t *curr, uint32_t num_levels,
                         float px, float py, float ex, float ey,
                         int termination, float epsilon, uint32_t num_iterations, int win,
-                        int sum_mode, float *ox, float *oy)
+                        int sum_mode, float *ox, float *oy, float *err)
 {
     const uint32_t w0 = prev[0].width, h0 = prev[0].height;
     if (!(px >= 0.0f && py >= 0.0f && px <= (float)(w0 - 1) && py <= (float)(h0 - 1))) return 0;
@@ -565,6 +568,38 @@ static int lk_track_one(const orc_image_t *prev, const orc_image_t *curr, uint32
     const float rx = px + (gx + vx), ry = py + (gy + vy);
     if (!(rx >= 0.0f && ry >= 0.0f && rx <= (float)(w0 - 1) && ry <= (float)(h0 - 1))) return 0;
     *ox = rx; *oy = ry;
+    if (err) {   /* level 0: Iw still holds its template; (px + gx) + vx is the position an iteration would sample */
+        const orc_image_t *J = &curr[0];
+        const float cx = (px + gx) + vx, cy = (py + gy) + vy;
+        const float jfx = floorf(cx), jfy = floorf(cy);
+        const float bx_ = cx - jfx, by_ = cy - jfy;
+        const int jx = (int)jfx - half, jy = (int)jfy - half;
+        float total;
+        if (sum_mode == ORC_SUM_WAVE64) {
+            float pe[64] = { 0 };
+            for (int l = 0; l < map.lanes; ++l) {
+                int row = l / map.segs, x0 = (l % map.segs) * map.seglen;
+                float a = 0.0f;
+                for (int k = 0; k < map.seglen && x0 + k < win; ++k) {
+                    int wx = x0 + k, j = row * win + wx, x = jx + wx, y = jy + row;
+                    float jv = bilerp(pix(J, x, y), pix(J, x + 1, y), pix(J, x, y + 1), pix(J, x + 1, y + 1), bx_, by_);
+                    a = a + fabsf(Iw[j] - jv);
+                }
+                pe[l] = a;
+            }
+            total = tree64(pe);
+        } else {
+            double a = 0;
+            for (int wy = 0; wy < win; ++wy)
+                for (int wx = 0; wx < win; ++wx) {
+                    int j = wy * win + wx, x = jx + wx, y = jy + wy;
+                    float jv = bilerp(pix(J, x, y), pix(J, x + 1, y), pix(J, x, y + 1), pix(J, x + 1, y + 1), bx_, by_);
+                    a += fabs((double)Iw[j] - jv);
+                }
+            total = (float)a;
+        }
+        *err = total * (1.0f / (float)(win * win));
+    }
     return 1;
 }
 
@@ -572,7 +607,7 @@ void orc_optical_flow_pyr_lk(const orc_image_t *prev_levels, const orc_image_t *
                              uint32_t num_levels,
                              int item_type, const void *prev_pts, void *pts_inout, uint32_t n,
                              int termination, float epsilon, uint32_t num_iterations,
-                             uint32_t window, int sum_mode)
+                             uint32_t window, int sum_mode, int calc_error)
 {
     if (window < 3 || window > LK_MAX_WIN || num_levels < 1) return;
 #ifdef _OPENMP
@@ -584,20 +619,21 @@ void orc_optical_flow_pyr_lk(const orc_image_t *prev_levels, const orc_image_t *
             const orc_point2f_t *p = (const orc_point2f_t *)prev_pts + i;
             orc_point2f_t *q = (orc_point2f_t *)pts_inout + i;
             int ok = lk_track_one(prev_levels, curr_levels, num_levels, p->x, p->y, q->x, q->y,
-                                  termination, epsilon, num_iterations, (int)window, sum_mode, &ox, &oy);
+                                  termination, epsilon, num_iterations, (int)window, sum_mode, &ox, &oy, NULL);
             if (ok) { q->x = ox; q->y = oy; } else { q->x = -1.0f; q->y = -1.0f; }
         } else {
             const orc_keypointf_t *p = (const orc_keypointf_t *)prev_pts + i;
             orc_keypointf_t *q = (orc_keypointf_t *)pts_inout + i;
-            float ex = q->x, ey = q->y;
+            float ex = q->x, ey = q->y, err = 0.0f;
             int ok = 0;
             if (p->tracking_status != 0)
                 ok = lk_track_one(prev_levels, curr_levels, num_levels, p->x, p->y, ex, ey,
-                                  termination, epsilon, num_iterations, (int)window, sum_mode, &ox, &oy);
+                                  termination, epsilon, num_iterations, (int)window, sum_mode, &ox, &oy,
+                                  calc_error ? &err : NULL);
             q->strength = p->strength;
             q->scale = p->scale;
             q->orientation = p->orientation;
-            q->error = 0.0f;
+            q->error = ok ? err : 0.0f;
             if (ok) { q->x = ox; q->y = oy; q->tracking_status = 255; }
             else    { q->x = ex; q->y = ey; q->tracking_status = 0; }
         }

@@ -89,7 +89,7 @@ void orc_optical_flow_pyr_lk(const orc_image_t *prev_levels, const orc_image_t *
                              uint32_t num_levels,
                              int item_type, const void *prev_pts, void *pts_inout, uint32_t n,
                              int termination, float epsilon, uint32_t num_iterations,
-                             uint32_t window, int sum_mode);
+                             uint32_t window, int sum_mode, int calc_error);
 
 /* nvxFindHomographyNode (RANSAC): demos/video_stabilizer/stabilizer.cpp:264-273, SfM.cpp:1576-1578.
  * src/dst: n x {f32 x,y}; H_out: 9 floats, element [3*c + r] = H[r][c] (homography_filter_node.cpp:87-91);

@@ -237,7 +237,7 @@ def _lk_case(w, h, levels, seed, dx, dy, n, item_type=O.POINT2F):
     return p0, p1, kp
 
 
-def _run_lk(p0, p1, pts, est, item_type, term, eps, iters, win, pitch_pad=None):
+def _run_lk(p0, p1, pts, est, item_type, term, eps, iters, win, pitch_pad=None, calc_error=0):
     h, w = p0[0].shape
     d0 = DevicePyramid(w, h, len(p0), pitch_pad=pitch_pad).upload(p0)
     d1 = DevicePyramid(w, h, len(p1), pitch_pad=pitch_pad).upload(p1)
@@ -245,7 +245,8 @@ def _run_lk(p0, p1, pts, est, item_type, term, eps, iters, win, pitch_pad=None):
     old = DeviceArray(len(pts) + 3, it).upload(pts)
     new = DeviceArray(len(pts) + 3, it).upload(pts if est is None else est)
     new.count.fill_(0)   # the primitive sets the output count itself
-    st = nvxcu.optical_flow_pyr_lk(d0.desc, d1.desc, old.desc, new.desc, term, eps, iters, win, current_target())
+    st = nvxcu.optical_flow_pyr_lk(d0.desc, d1.desc, old.desc, new.desc, term, eps, iters, win, current_target(),
+                                   calc_error=calc_error)
     assert st == OK
     sync()
     assert new.num_items() == len(pts)           # object_tracker_keypoint_nvxcu.cpp:1862-1863
@@ -321,6 +322,49 @@ def test_pyrlk_initial_estimates_and_keypointf(gpu):
     assert got.tobytes() == want.tobytes()
     assert set(np.unique(got["tracking_status"])) <= {0, 255}
     np.testing.assert_array_equal(got["strength"], kp["strength"])   # object_tracker_keypoint_nvxcu.cpp:1912
+
+
+@pytest.mark.parametrize("win", [5, 10, 21, 32])
+def test_pyrlk_calc_error(gpu, win):
+    """calcError (argument 9 of nvxcuOpticalFlowPyrLK, object_tracker_keypoint_nvxcu.cpp:1799): the error field of
+    tracked KEYPOINTF items, bit for bit; POINT2F items are unaffected by the flag"""
+    p0, p1, kp = _lk_case(320, 240, 4, seed=40 + win, dx=2.3, dy=-1.1, n=500, item_type=O.KEYPOINTF)
+    got = _run_lk(p0, p1, kp, None, O.KEYPOINTF, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 0.01, 5, win, calc_error=1)
+    want = O.optical_flow_pyr_lk(p0, p1, kp, None, O.TERM_BOTH, 0.01, 5, win, item_type=O.KEYPOINTF, calc_error=True)
+    assert got.tobytes() == want.tobytes()
+    tracked = got["tracking_status"] == 255
+    assert tracked.sum() > 100 and (got["error"][tracked] > 0).all() and (got["error"][~tracked] == 0).all()
+    ref = O.optical_flow_pyr_lk(p0, p1, kp, None, O.TERM_BOTH, 0.01, 5, win, item_type=O.KEYPOINTF, calc_error=True,
+                                sum_mode=O.SUM_F64SEQ)
+    both = tracked & (ref["tracking_status"] == 255)
+    assert np.abs(got["error"][both] - ref["error"][both]).max() < 0.05      # grey levels; float64 raster-order sums
+    off = _run_lk(p0, p1, kp, None, O.KEYPOINTF, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 0.01, 5, win, calc_error=0)
+    assert (off["error"] == 0).all()
+    for f in ("x", "y", "tracking_status", "strength"):
+        np.testing.assert_array_equal(off[f], got[f])
+    xy = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
+    a = _run_lk(p0, p1, xy, None, O.POINT2F, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 0.01, 5, win, calc_error=1)
+    b = _run_lk(p0, p1, xy, None, O.POINT2F, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 0.01, 5, win, calc_error=0)
+    assert a.tobytes() == b.tobytes()
+
+
+def test_pyrlk_forward_backward_check_like_the_object_tracker(gpu):
+    """samples/object_tracker_nvxcu/object_tracker_keypoint_nvxcu.cpp:1780-1828, 1875-1905: points0 -> points1 on
+    (prev, curr), then points1 -> pointsFb on (curr, prev), each seeded with a copy of its input; a point is kept when
+    both passes report 255 and the round trip closes.  Both passes bit-identical to the oracle."""
+    p0, p1, kp0 = _lk_case(640, 480, 5, seed=9, dx=3.7, dy=-2.4, n=1200, item_type=O.KEYPOINTF)
+    fwd = _run_lk(p0, p1, kp0, kp0, O.KEYPOINTF, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 0.01, 20, 21)
+    bwd = _run_lk(p1, p0, fwd, fwd, O.KEYPOINTF, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 0.01, 20, 21)
+    want_f = O.optical_flow_pyr_lk(p0, p1, kp0, kp0, O.TERM_BOTH, 0.01, 20, 21, item_type=O.KEYPOINTF)
+    want_b = O.optical_flow_pyr_lk(p1, p0, want_f, want_f, O.TERM_BOTH, 0.01, 20, 21, item_type=O.KEYPOINTF)
+    assert fwd.tobytes() == want_f.tobytes() and bwd.tobytes() == want_b.tobytes()
+    both = (fwd["tracking_status"] == 255) & (bwd["tracking_status"] == 255)
+    assert both.sum() > 400
+    fb = np.hypot(bwd["x"] - kp0["x"], bwd["y"] - kp0["y"])[both]
+    assert np.median(fb) < 0.05 and (fb < 1.0).mean() > 0.95               # maxBackwardCheckingError-style gate
+    np.testing.assert_array_equal(bwd["strength"], kp0["strength"])         # :1912 relies on it
+    # a lost forward point is not resurrected by the backward pass
+    assert (bwd["tracking_status"][fwd["tracking_status"] == 0] == 0).all()
 
 
 def test_pyrlk_flat_image_loses_everything(gpu):

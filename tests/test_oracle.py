@@ -227,6 +227,16 @@ def test_pyrlk_contract_count_order_lost_encoding():
     assert ko["tracking_status"].tolist() == [255, 0, 0]
     np.testing.assert_array_equal(ko["strength"], kp["strength"])
     assert (ko["error"] == 0).all()
+    # calcError: mean |I - J| at the final position -- ~0 between identical frames, small after a good track,
+    # the same in both summation orders up to rounding, 0 for lost points
+    ke = O.optical_flow_pyr_lk(p0, p1, kp, None, O.TERM_BOTH, 0.01, 5, 7, item_type=O.KEYPOINTF, calc_error=True)
+    for f in ("x", "y", "tracking_status", "strength"):
+        np.testing.assert_array_equal(ke[f], ko[f])
+    assert 0 < ke["error"][0] < 6.0 and (ke["error"][1:] == 0).all()
+    k64 = O.optical_flow_pyr_lk(p0, p1, kp, None, O.TERM_BOTH, 0.01, 5, 7, item_type=O.KEYPOINTF, calc_error=True, sum_mode=O.SUM_F64SEQ)
+    assert abs(float(k64["error"][0]) - float(ke["error"][0])) < 0.02
+    ks = O.optical_flow_pyr_lk(p0, p0, kp, None, O.TERM_BOTH, 0.01, 5, 7, item_type=O.KEYPOINTF, calc_error=True)
+    assert ks["tracking_status"][0] == 255 and ks["error"][0] < 0.05
     flat = [np.full((30 >> l, 40 >> l), 50, np.uint8) for l in range(2)]
     np.testing.assert_array_equal(O.optical_flow_pyr_lk(flat, flat, np.array([[20, 15]], np.float32), window=5), [[-1, -1]])
     same = O.optical_flow_pyr_lk(p0, p0, pts[[1, 4]], None, O.TERM_BOTH, 0.01, 5, 7)

@@ -104,6 +104,7 @@ struct PyrLKParams {
     uint32_t max_iterations;
     float epsilon;
     uint32_t window;
+    bool calc_error = false;      // KEYPOINTF: error = mean |I - J| over the level-0 window at the final position
 };
 
 // one kernel (pyrlk.hip): aligned dword staging when every level is 4-byte aligned, per-byte clamped loads

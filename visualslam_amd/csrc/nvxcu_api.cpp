@@ -223,7 +223,6 @@ nvxcu_error_status_e nvxcuOpticalFlowPyrLK(const nvxcu_pyramid_t *old_pyramid, c
     hipStream_t stream;
     if (!get_stream(exec_target, &stream)) return NVXCU_ERROR_INVALID_PARAMETERS;
     if (border && border->mode == NVXCU_BORDER_MODE_CONSTANT) return NVXCU_ERROR_NOT_SUPPORTED;
-    if (calc_error) return NVXCU_ERROR_NOT_SUPPORTED;
     if (window_dimension < (uint32_t)kLkMinWin || window_dimension > (uint32_t)kLkMaxWin)
         return NVXCU_ERROR_INVALID_PARAMETERS;
     if (termination != NVXCU_TERM_CRITERIA_ITERATIONS && termination != NVXCU_TERM_CRITERIA_EPSILON &&
@@ -255,6 +254,7 @@ nvxcu_error_status_e nvxcuOpticalFlowPyrLK(const nvxcu_pyramid_t *old_pyramid, c
     p.max_iterations = termination == NVXCU_TERM_CRITERIA_EPSILON ? 100u : num_iterations;
     p.epsilon = epsilon;
     p.window = window_dimension;
+    p.calc_error = calc_error != 0;      // fills nvxcu_keypointf_t::error; POINT2F items have no such field
     return from_hip(launch_pyrlk(p, stream));
 }
 

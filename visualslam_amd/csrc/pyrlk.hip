@@ -48,6 +48,7 @@ struct LKArgs {
     uint32_t max_it;
     float eps2;
     int win, half, segs, seglen, lanes;
+    int calc_error;
 };
 
 struct KeypointF {
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     const float fw = (float)win;
 
     float Iw[NSEG], Ix[NSEG], Iy[NSEG];
+    float err = 0.0f;
 
     TileRegs<NLP> tp;
     TileRegs<NLJ> tj;
@@ -353,6 +355,35 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             if (a.use_eps && fmaf(etx, etx, ety * ety) < a.eps2) break;
         }
         if (L > 0) { gx = 2.0f * (gx + vx); gy = 2.0f * (gy + vy); }
+        else if (a.calc_error && ok) {
+            // calcError: mean |I - J| over the window at the final position of level 0 (the position an iteration
+            // would sample next); the template is still in registers, the search tile in LDS
+            const float cx = (ux + gx) + vx, cy = (uy + gy) + vy;
+            if (cx > -fw && cy > -fw && cx < flw + fw && cy < flh + fw) {
+                const float jfx = floorf(cx), jfy = floorf(cy);
+                const float bx = cx - jfx, by = cy - jfy;
+                const int jx = __builtin_amdgcn_readfirstlane((int)jfx) - half, jy = __builtin_amdgcn_readfirstlane((int)jfy) - half;
+                int ox = jx - jx0, oy = jy - jy0;
+                if (ox < 0 || oy < 0 || ox > 2 * LK_MARGIN || oy > 2 * LK_MARGIN) {
+                    jx0 = jx - LK_MARGIN; jy0 = jy - LK_MARGIN; ox = LK_MARGIN; oy = LK_MARGIN;
+                    tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
+                    __syncthreads();
+                    tile_commit(tj, J, lane);
+                    __syncthreads();
+                }
+                const float *jt = J + lbaseJ + (oy * JS + (jx0 & 3) + ox);
+                float cp = fmaf(by, jt[JS] - jt[0], jt[0]);
+                float e = 0.0f;
+#pragma unroll
+                for (int k = 0; k < NSEG; ++k) {
+                    const float cc = fmaf(by, jt[JS + k + 1] - jt[k + 1], jt[k + 1]);
+                    const float jv = fmaf(bx, cc - cp, cp);
+                    e = e + (k < cnt ? fabsf(Iw[k] - jv) : 0.0f);
+                    cp = cc;
+                }
+                err = wave_sum(e) * (1.0f / (float)(win * win));
+            }
+        }
     }
 
     float rx = -1.0f, ry = -1.0f;
@@ -365,7 +396,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             reinterpret_cast<float2 *>(a.out)[pi] = ok ? make_float2(rx, ry) : make_float2(-1.0f, -1.0f);
         } else {
             KeypointF o = reinterpret_cast<const KeypointF *>(a.prev_pts)[pi];
-            o.error = 0.0f;
+            o.error = ok ? err : 0.0f;
             if (ok) { o.x = rx; o.y = ry; o.tracking_status = 255; }
             else    { o.x = ex; o.y = ey; o.tracking_status = 0; }
             reinterpret_cast<KeypointF *>(a.out)[pi] = o;
@@ -407,6 +438,7 @@ hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
     a.prev_pts = p.prev_pts; a.prev_count = p.prev_count; a.estimates = p.estimates;
     a.out = p.out; a.out_count = p.out_count; a.out_count_host = p.out_count_host; a.capacity = p.capacity;
     a.use_eps = p.use_epsilon; a.max_it = p.max_iterations; a.eps2 = p.epsilon * p.epsilon;
+    a.calc_error = p.calc_error ? 1 : 0;
     const int win = (int)p.window;
     a.win = win; a.half = win / 2;
     // lane map shared with the oracle (lk_map): segs x win lanes of seglen pixels
