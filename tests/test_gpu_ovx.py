@@ -282,3 +282,59 @@ def test_immediate_pyrlk_with_estimates_keypointf(ctx):
         want = O.optical_flow_pyr_lk(p0, p1, kp, e, O.TERM_BOTH, 0.01, 5, 10, item_type=O.KEYPOINTF)
         assert ovx.num_items(out) == 300
         assert ovx.read_array(out, O.keypointf_dtype).tobytes() == want.tobytes()
+
+
+def test_reference_demo_reads_an_image_sequence_and_logs_in_eventlogger_format(gpu, tmp_path):
+    """the headless shim's I/O formats under the reference's unmodified demo main -- a numbered PGM sequence
+    as the source (a '%' in the path, nvxio/src/NVX/FrameSource/FrameSource.cpp:198-328) and the EventLogger text format
+    (nvxio/src/NVX/Render/EventLogger.cpp) as the regression log; the tracked points still equal the oracle's."""
+    import re
+    import shutil
+    exe = os.path.join(ROOT, "oracle", "_ref", "nvx_demo_feature_tracker")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/nvx_demo_feature_tracker not built (needs /root/reference at build time)")
+    (tmp_path / "bin").mkdir()
+    (tmp_path / "data").mkdir()
+    run_exe = tmp_path / "bin" / "nvx_demo_feature_tracker"
+    shutil.copy(exe, run_exe)
+    w, h, n = 320, 240, 6
+    base = synth.base_frame(w, h, 5)
+    grays = [synth.gray_frame(base, t, 5) for t in range(n)]
+    for t, g in enumerate(grays):                                   # numbered from 1
+        with open(tmp_path / f"frame_{t + 1:04d}.pgm", "wb") as f:
+            f.write(b"P5\n# made by the test\n%d %d\n255\n" % (w, h) + np.ascontiguousarray(g).tobytes())
+    (tmp_path / "data" / "feature_tracker_demo_config.ini").write_text(
+        "pyr_levels = 3\nlk_num_iters = 5\nlk_win_size = 10\n\narray_capacity = 800\ndetector_cell_size = 18\n"
+        "detector = harris\n\nharris_k = 0.04\nharris_thresh = 100.0\n\nfast_type = 9\nfast_thresh = 25\n")
+    opath, lpath = tmp_path / "out.bin", tmp_path / "events.log"
+    env = dict(os.environ, VSA_HEADLESS_FRAMES=str(n - 1), VSA_HEADLESS_OUT=str(opath), VSA_HEADLESS_LOG=str(lpath),
+               LD_LIBRARY_PATH=os.path.join(ROOT, "visualslam_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    cmd = [str(run_exe), f"--source={tmp_path}/frame_%04d.pgm", "--nvxio_fps_limit=1000"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env)
+    if res.returncode != 0 and "nvxio_fps_limit" in (res.stdout + res.stderr):
+        res = subprocess.run(cmd[:2], capture_output=True, text=True, timeout=180, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    p = Params(pyr_levels=3, lk_num_iters=5, lk_win_size=10, array_capacity=800, use_harris_detector=True, harris_thresh=100.0)
+    ref = OracleTracker(p)
+    ref.init(synth.to_rgbx(grays[0]))
+    raw = np.fromfile(opath, np.uint8)
+    off, counts = 0, []
+    for t in range(1, n):
+        old, cur = ref.track(synth.to_rgbx(grays[t]))
+        counts.append(len(old))
+        for want in (old, cur):
+            cnt = int(raw[off:off + 4].view(np.uint32)[0]); off += 4
+            got = raw[off:off + 8 * cnt].view(np.float32).reshape(cnt, 2); off += 8 * cnt
+            assert got.tobytes() == want.tobytes(), f"frame {t}"
+    assert off == raw.size
+    lines = lpath.read_text().splitlines()
+    fmt = int.from_bytes(b"RGBA", "little")
+    for k in range(n - 1):                                            # one displayed frame per tracked frame
+        mine = [l for l in lines if l.startswith(f"{k}: ")]
+        assert f"{k}: image({fmt}, {w}x{h})" in mine
+        arrows = [l for l in mine if l.startswith(f"{k}: arrows(")]
+        assert len(arrows) == 1
+        m = re.fullmatch(rf"{k}: arrows\(color\((\d+),(\d+),(\d+),(\d+)\), thickness\((-?\d+)\), (\d+)\)", arrows[0])
+        assert m and int(m.group(6)) == counts[k]
+        assert any(re.fullmatch(rf'{k}: textBox\(color\(\d+,\d+,\d+,\d+\), bkcolor\(\d+,\d+,\d+,\d+\), origin\(\d+,\d+\), ".*"\)', l) for l in mine)
+    assert not any(l.startswith(f"{n - 1}: ") for l in lines)
