@@ -106,6 +106,7 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     torch.cuda.set_device(local_rank)
+    os.environ["VISUALSLAM_AMD_DEVICE"] = str(local_rank)      # vxCreateContext binds this rank's GPU explicitly
     device = f"cuda:{local_rank}"
     nvxcu.lib()
 

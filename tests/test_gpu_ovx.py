@@ -338,3 +338,19 @@ def test_reference_demo_reads_an_image_sequence_and_logs_in_eventlogger_format(g
         assert m and int(m.group(6)) == counts[k]
         assert any(re.fullmatch(rf'{k}: textBox\(color\(\d+,\d+,\d+,\d+\), bkcolor\(\d+,\d+,\d+,\d+\), origin\(\d+,\d+\), ".*"\)', l) for l in mine)
     assert not any(l.startswith(f"{n - 1}: ") for l in lines)
+
+
+def test_context_device_override(gpu, monkeypatch):
+    """VISUALSLAM_AMD_DEVICE: one process per GPU launchers (bench.py's ranks) name their GPU explicitly"""
+    import torch
+    monkeypatch.setenv("VISUALSLAM_AMD_DEVICE", "0")
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    img = L.vxCreateImage(c, 16, 16, ovx.VX_DF_IMAGE_U8)
+    ovx.write_image(img, np.full((16, 16), 7, np.uint8))
+    assert (ovx.read_image(img) == 7).all()
+    assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
+    monkeypatch.setenv("VISUALSLAM_AMD_DEVICE", str(torch.cuda.device_count()))
+    c = L.vxCreateContext()
+    assert c and L.vxGetStatus(c) == ovx.VX_ERROR_INVALID_PARAMETERS          # no such GPU: an error context, not a crash
+    assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS

@@ -1306,6 +1306,12 @@ vx_context vxCreateContext(void)
         ctx->status = (vx_status)NVX_ERROR_NO_GPU;
         return ctx;
     }
+    // the context binds the calling thread's current device; VISUALSLAM_AMD_DEVICE=<ordinal> overrides it (one process
+    // per GPU launchers that cannot call hipSetDevice themselves, e.g. bench.py's ranks)
+    if (const char *dev = getenv("VISUALSLAM_AMD_DEVICE")) {
+        const int want = atoi(dev);
+        if (want < 0 || want >= count || hipSetDevice(want) != hipSuccess) { ctx->status = VX_ERROR_INVALID_PARAMETERS; return ctx; }
+    }
     if (hipGetDevice(&ctx->device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
