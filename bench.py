@@ -105,9 +105,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    os.environ["VISUALSLAM_AMD_DEVICE"] = str(local_rank)      # vxCreateContext binds this rank's GPU explicitly
-    device = f"cuda:{local_rank}"
+    # one GPU per rank; on a box with fewer GPUs than ranks (a rehearsal) ranks share GPUs round-robin
+    local_device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_device)
+    os.environ["VISUALSLAM_AMD_DEVICE"] = str(local_device)     # vxCreateContext binds this rank's GPU explicitly
+    device = f"cuda:{local_device}"
     nvxcu.lib()
 
     params = Params(pyr_levels=LEVELS, lk_num_iters=ITERS, lk_win_size=WIN, array_capacity=CAPACITY,
