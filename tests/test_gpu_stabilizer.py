@@ -314,3 +314,29 @@ def test_reference_video_stabilizer_demo_compiled_unmodified_runs(gpu, tmp_path)
     assert np.mean(raw_motion) > 2.0
     assert np.mean(stab_motion) < 0.5 * np.mean(raw_motion), (np.mean(stab_motion), np.mean(raw_motion))
     assert imgs[-1][:, w:, :3].any()
+
+
+def test_warp_perspective_edge_cases(ctx):
+    """tiny and degenerate inputs: a 1x1 source, single rows/columns, a singular and an all-zero matrix (every pixel takes
+    the border), infinities in the matrix -- always the oracle's bytes, never a fault"""
+    rng = np.random.default_rng(12)
+    cases = [((1, 1), (5, 7)), ((1, 9), (9, 1)), ((13, 1), (4, 4)), ((3, 2), (64, 5)), ((2, 300), (300, 2))]
+    mats = [np.eye(3), np.zeros((3, 3)), np.array([[1, 2, 3], [2, 4, 6], [0, 0, 0.0]]),
+            np.array([[0.5, 0, 0], [0, 0.5, 0], [0, 0, 1.0]]), np.array([[1, 0, np.inf], [0, 1, 0], [0, 0, 1.0]]),
+            np.array([[1, 0, 0], [0, 1, 0], [1e30, 1e30, 1.0]]), np.array([[-1, 0, 0], [0, -1, 0], [0, 0, 1.0]])]
+    for fmt, vfmt in (("u8", ovx.VX_DF_IMAGE_U8), ("rgbx", ovx.VX_DF_IMAGE_RGBX)):
+        for (sh, sw), (oh, ow) in cases:
+            img_np = rng.integers(0, 256, (sh, sw) if fmt == "u8" else (sh, sw, 4), dtype=np.uint8)
+            src = L.vxCreateImage(ctx, sw, sh, vfmt)
+            dst = L.vxCreateImage(ctx, ow, oh, vfmt)
+            ovx.write_image(src, img_np)
+            for M in mats:
+                with np.errstate(all="ignore"):
+                    m, data = _matrix(ctx, M)
+                for vint, bil in ((ovx.VX_INTERPOLATION_BILINEAR, True), (ovx.VX_INTERPOLATION_NEAREST_NEIGHBOR, False)):
+                    ovx.check(L.vxuWarpPerspective(ctx, src, m, vint, dst))
+                    want = O.warp_perspective(img_np, data, (oh, ow), bilinear=bil)
+                    assert ovx.read_image(dst).tobytes() == want.tobytes(), (fmt, sh, sw, oh, ow, M.tolist(), bil)
+                ovx.release("Matrix", m)
+            ovx.release("Image", src)
+            ovx.release("Image", dst)
