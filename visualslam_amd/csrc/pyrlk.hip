@@ -83,19 +83,22 @@ __device__ __forceinline__ float wave_sum(float v)
 
 // ---- tile staging ----------------------------------------------------------------------------
 // A tile with origin (x0,y0) is fetched as rows of ND aligned dwords starting at column
-// xa = floor4(x0).  Slot s = lane + 64*i is (row s / ND, dword s % ND) and lands in LDS as the four floats
-// [4*s .. 4*s+3]: tile element (r,c) lives at r*4*ND + (x0-xa) + c.  Slots past the last tile row
-// fetch (clamped) rows below it; they only fill LDS that nobody interprets.
+// xa = floor4(x0).  Slot s = lane + 64*i is (row s / ND, dword s % ND) and lands in LDS as four floats at float4
+// index row*LS4 + dword: tile element (r,c) lives at r*4*LS4 + (x0-xa) + c.  LS4 >= ND is the LDS row stride in
+// float4 units, chosen ODD so that the rows a wave reads together start in different banks (a stride of 8 float4 =
+// 32 floats put every other row on the same banks: 43% of PyrLK's LDS cycles were bank conflicts).  Slots past
+// the last tile row fetch (clamped) rows below it; they only fill LDS that nobody interprets.
 template <int NL>
 struct TileSlots {
     int row[NL], col4[NL];   // this lane's slots: tile row and byte offset 4*dword inside the row (level-invariant)
+    int lds4[NL];            // float4 index of the slot in LDS
 };
 template <int NL>
 struct TileRegs {
     uint32_t v[NL];
 };
 
-template <int NL, int ND>
+template <int NL, int ND, int LS4>
 __device__ __forceinline__ void tile_slots(TileSlots<NL> &s, int lane)
 {
 #pragma unroll
@@ -103,6 +106,7 @@ __device__ __forceinline__ void tile_slots(TileSlots<NL> &s, int lane)
         const int idx = lane + 64 * i;
         s.row[i] = idx / ND;
         s.col4[i] = 4 * (idx - s.row[i] * ND);
+        s.lds4[i] = s.row[i] * LS4 + (idx - s.row[i] * ND);
     }
 }
 
@@ -133,13 +137,13 @@ __device__ __forceinline__ void tile_issue(TileRegs<NL> &t, const TileSlots<NL> 
 }
 
 template <int NL>
-__device__ __forceinline__ void tile_commit(const TileRegs<NL> &t, float *dst, int lane)
+__device__ __forceinline__ void tile_commit(const TileRegs<NL> &t, const TileSlots<NL> &s, float *dst)
 {
-    float4 *d4 = reinterpret_cast<float4 *>(dst) + lane;
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const uint32_t v = t.v[i];
-        d4[64 * i] = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+        d4[s.lds4[i]] = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
     }
 }
 
@@ -154,8 +158,10 @@ template <int NSEG, int WMAX, bool ALIGNED>
 __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 {
     constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;   // dwords per tile row
-    constexpr int PS = 4 * NDP, JS = 4 * NDJ;                                              // LDS row strides (floats)
+    constexpr int PS4 = NDP | 1, JS4 = NDJ | 1;                                            // LDS row strides (float4), odd
+    constexpr int PS = 4 * PS4, JS = 4 * JS4;                                              // ... in floats
     constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
+    constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * PS, JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * JS;   // tile regions
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -205,13 +211,13 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 
     // LDS only ever holds converted pixels or these zeros (the slack a lane may over-read past its
     // segment at the end of either tile region), so idle pixels multiply finite values by exact zeros
-    smem[NLP * 256 + lane] = 0.0f;
-    smem[NLJ * 256 + lane] = 0.0f;
+    smem[PFLOATS + lane] = 0.0f;
+    smem[JFLOATS + lane] = 0.0f;
 
     TileSlots<NLP> sp;
     TileSlots<NLJ> sj;
-    tile_slots<NLP, NDP>(sp, lane);
-    tile_slots<NLJ, NDJ>(sj, lane);
+    tile_slots<NLP, NDP, PS4>(sp, lane);
+    tile_slots<NLJ, NDJ, JS4>(sj, lane);
 
     const int top = (int)a.prev.levels - 1;
     const float s_top = 1.0f / (float)(1u << top);
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
 
         __syncthreads();   // previous level's search tile is dead
-        tile_commit(tp, P, lane);
+        tile_commit(tp, sp, P);
         __syncthreads();
 
         // template pass, streaming over the lane's P columns c = 0 .. NSEG+2 (four rows each):
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         const float flw = (float)lw, flh = (float)lh;
 
         __syncthreads();   // every lane is done with P
-        tile_commit(tj, J, lane);
+        tile_commit(tj, sj, J);
         __syncthreads();
 
         for (uint32_t it = 0; it < a.max_it; ++it) {
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
                 jx0 = jx - LK_MARGIN; jy0 = jy - LK_MARGIN; ox = LK_MARGIN; oy = LK_MARGIN;
                 tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
                 __syncthreads();
-                tile_commit(tj, J, lane);
+                tile_commit(tj, sj, J);
                 __syncthreads();
             }
 #ifdef VSA_LK_STAMPS
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
                     jx0 = jx - LK_MARGIN; jy0 = jy - LK_MARGIN; ox = LK_MARGIN; oy = LK_MARGIN;
                     tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
                     __syncthreads();
-                    tile_commit(tj, J, lane);
+                    tile_commit(tj, sj, J);
                     __syncthreads();
                 }
                 const float *jt = J + lbaseJ + (oy * JS + (jx0 & 3) + ox);
@@ -417,7 +423,8 @@ hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipSt
 {
     constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;
     constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
-    constexpr size_t lds = ((NLP > NLJ ? NLP : NLJ) * 256 + 64) * sizeof(float);   // slots + zeroed slack
+    constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * 4 * (NDP | 1), JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * 4 * (NDJ | 1);
+    constexpr size_t lds = ((PFLOATS > JFLOATS ? PFLOATS : JFLOATS) + 64) * sizeof(float);   // tile region + zeroed slack
     const dim3 grid(capacity), block(64);
     if (aligned) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false>), grid, block, lds, stream, a);
