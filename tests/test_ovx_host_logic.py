@@ -639,3 +639,30 @@ def test_warp_perspective_node_verification(ctx):
     assert verify(a, m23, ovx.VX_INTERPOLATION_BILINEAR, b)[1] == ovx.VX_ERROR_INVALID_DIMENSION
     assert verify(a, None, ovx.VX_INTERPOLATION_BILINEAR, b)[1] == ovx.VX_ERROR_INVALID_PARAMETERS
     assert L.vxuWarpPerspective(ctx, a, m, ovx.VX_INTERPOLATION_BILINEAR, b) == ovx.NVX_ERROR_NO_GPU
+
+
+def test_objects_shared_by_graphs_on_different_threads(ctx):
+    """bench.py drives one graph per camera stream from its own host thread, all rebinding frames of ONE shared ring
+    every frame (vxSetParameterByIndex, feature_tracker.cpp:216): reference counts must survive that"""
+    import threading
+    shared = [L.vxCreateImage(ctx, 64, 48, ovx.VX_DF_IMAGE_RGBX) for _ in range(2)]
+    nodes = []
+    for _ in range(8):
+        g = L.vxCreateGraph(ctx)
+        out = L.vxCreateImage(ctx, 64, 48, ovx.VX_DF_IMAGE_U8)
+        n = L.vxColorConvertNode(g, shared[0], out)
+        assert L.vxGetStatus(n) == ovx.VX_SUCCESS and L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+        nodes.append(n)
+
+    def work(n):
+        for k in range(20000):
+            L.vxSetParameterByIndex(n, 0, shared[k & 1])
+
+    ths = [threading.Thread(target=work, args=(n,)) for n in nodes]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    # every node ends bound to shared[1] (k = 19999): the creator's reference + one per node; shared[0] only the creator's
+    assert ovx.query("vxQueryReference", shared[1], ovx.VX_REFERENCE_COUNT, C.c_uint32) == 1 + len(nodes)
+    assert ovx.query("vxQueryReference", shared[0], ovx.VX_REFERENCE_COUNT, C.c_uint32) == 1

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -42,7 +43,7 @@ struct _vx_reference {
     uint32_t magic = kMagic;
     vx_enum type = VX_TYPE_INVALID;
     _vx_context *ctx = nullptr;
-    int refs = 1;
+    std::atomic<int> refs{1};         // graphs of different camera streams run on different host threads and share objects (frames)
     vx_status status = VX_SUCCESS;    // != SUCCESS only for error objects / a GPU-less context
     _vx_delay *delay = nullptr;       // owning delay, if this object is a delay slot
 };
@@ -230,7 +231,7 @@ void track(_vx_context *ctx, _vx_reference *r)
     ctx->live.insert(r);
 }
 
-void retain(_vx_reference *r) { if (r) ++r->refs; }
+void retain(_vx_reference *r) { if (r) r->refs.fetch_add(1, std::memory_order_relaxed); }
 void release_ref(_vx_reference *r);
 
 bool usable(_vx_context *ctx) { return valid(ctx, VX_TYPE_CONTEXT); }
@@ -388,7 +389,7 @@ void destroy(_vx_reference *r)
 void release_ref(_vx_reference *r)
 {
     if (!valid(r) || r->type == VX_TYPE_ERROR || r->type == VX_TYPE_CONTEXT) return;
-    if (--r->refs <= 0) destroy(r);
+    if (r->refs.fetch_sub(1, std::memory_order_acq_rel) <= 1) destroy(r);
 }
 
 template <typename H>
@@ -1415,7 +1416,7 @@ vx_status vxQueryReference(vx_reference ref, vx_enum attribute, void *ptr, vx_si
 {
     if (!valid(ref)) return VX_ERROR_INVALID_REFERENCE;
     switch (attribute) {
-    case VX_REFERENCE_COUNT: { vx_uint32 v = (vx_uint32)ref->refs; return query_out(ptr, size, &v, sizeof(v)); }
+    case VX_REFERENCE_COUNT: { vx_uint32 v = (vx_uint32)ref->refs.load(); return query_out(ptr, size, &v, sizeof(v)); }
     case VX_REFERENCE_TYPE: { vx_enum v = ref->type; return query_out(ptr, size, &v, sizeof(v)); }
     default: return VX_ERROR_NOT_SUPPORTED;
     }
