@@ -68,6 +68,7 @@ typedef struct _vx_delay     *vx_delay;
 typedef struct _vx_scalar    *vx_scalar;
 typedef struct _vx_kernel    *vx_kernel;
 typedef struct _vx_meta_format *vx_meta_format;
+typedef struct _vx_parameter *vx_parameter;
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum vx_status_e {
@@ -451,6 +452,26 @@ VX_API_ENTRY vx_node VX_API_CALL vxCreateGenericNode(vx_graph graph, vx_kernel k
 /* homography_filter_node.cpp:197-199: the validator describes each output; vxVerifyGraph compares it with the object bound */
 VX_API_ENTRY vx_status VX_API_CALL vxSetMetaFormatAttribute(vx_meta_format meta, vx_enum attribute, const void *ptr, vx_size size);
 VX_API_ENTRY vx_status VX_API_CALL vxSetMetaFormatFromReference(vx_meta_format meta, vx_reference exemplar);
+
+/* OpenVX 1.0 form of the same, as the SFM sample's scaleCloud kernel uses it (sfm/SfM.cpp:1204-1400): one validator call
+ * per input parameter and per output parameter; validators reach the bound object through a vx_parameter. */
+typedef vx_status (VX_CALLBACK *vx_kernel_input_validate_f)(vx_node node, vx_uint32 index);
+typedef vx_status (VX_CALLBACK *vx_kernel_output_validate_f)(vx_node node, vx_uint32 index, vx_meta_format meta);
+enum vx_parameter_attribute_e {
+    VX_PARAMETER_INDEX = 0x80500, VX_PARAMETER_DIRECTION, VX_PARAMETER_TYPE, VX_PARAMETER_STATE, VX_PARAMETER_REF,
+    VX_PARAMETER_ATTRIBUTE_INDEX = VX_PARAMETER_INDEX, VX_PARAMETER_ATTRIBUTE_DIRECTION = VX_PARAMETER_DIRECTION,
+    VX_PARAMETER_ATTRIBUTE_TYPE = VX_PARAMETER_TYPE, VX_PARAMETER_ATTRIBUTE_STATE = VX_PARAMETER_STATE,
+    VX_PARAMETER_ATTRIBUTE_REF = VX_PARAMETER_REF
+};
+VX_API_ENTRY vx_kernel VX_API_CALL vxAddKernel(vx_context context, const vx_char name[VX_MAX_KERNEL_NAME], vx_enum enumeration,
+                                               vx_kernel_f func_ptr, vx_uint32 numParams, vx_kernel_input_validate_f input,
+                                               vx_kernel_output_validate_f output, vx_kernel_initialize_f init,
+                                               vx_kernel_deinitialize_f deinit);
+/* SfM.cpp:1211-1235: a +1 reference to the parameter; VX_PARAMETER_REF hands out a +1 reference to the bound object
+ * (NULL when nothing is bound), which the caller releases */
+VX_API_ENTRY vx_parameter VX_API_CALL vxGetParameterByIndex(vx_node node, vx_uint32 index);
+VX_API_ENTRY vx_status VX_API_CALL vxQueryParameter(vx_parameter param, vx_enum attribute, void *ptr, vx_size size);
+VX_API_ENTRY vx_status VX_API_CALL vxReleaseParameter(vx_parameter *param);
 
 #ifdef __cplusplus
 }

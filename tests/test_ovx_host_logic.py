@@ -666,3 +666,54 @@ def test_objects_shared_by_graphs_on_different_threads(ctx):
     # every node ends bound to shared[1] (k = 19999): the creator's reference + one per node; shared[0] only the creator's
     assert ovx.query("vxQueryReference", shared[1], ovx.VX_REFERENCE_COUNT, C.c_uint32) == 1 + len(nodes)
     assert ovx.query("vxQueryReference", shared[0], ovx.VX_REFERENCE_COUNT, C.c_uint32) == 1
+
+
+def test_openvx_1_0_kernel_api(ctx):
+    """vxAddKernel with per-parameter validators reaching the bound objects through vx_parameter, as the SFM sample's
+    scaleCloud kernel does (sfm/SfM.cpp:1204-1400)"""
+    calls = []
+
+    def in_validate(node, index):
+        p = L.vxGetParameterByIndex(node, index)
+        assert L.vxGetStatus(p) == ovx.VX_SUCCESS
+        ref = C.c_void_p()
+        assert L.vxQueryParameter(p, ovx.VX_PARAMETER_REF, C.byref(ref), 8) == ovx.VX_SUCCESS
+        assert ovx.query("vxQueryParameter", p, ovx.VX_PARAMETER_INDEX, C.c_uint32) == index
+        assert ovx.query("vxQueryParameter", p, ovx.VX_PARAMETER_DIRECTION, C.c_int32) == ovx.VX_INPUT
+        rows = ovx.query("vxQueryMatrix", ref.value, ovx.VX_MATRIX_ROWS, C.c_size_t)
+        cols = ovx.query("vxQueryMatrix", ref.value, ovx.VX_MATRIX_COLUMNS, C.c_size_t)
+        calls.append(("in", index, rows, cols))
+        assert ovx.release("Matrix", ref.value) == ovx.VX_SUCCESS          # VX_PARAMETER_REF hands out a reference
+        assert L.vxReleaseParameter(C.byref(C.c_void_p(p))) == ovx.VX_SUCCESS
+        return ovx.VX_SUCCESS if (rows, cols) == (1, 3) else ovx.VX_ERROR_INVALID_PARAMETERS
+
+    def out_validate(node, index, meta):
+        calls.append(("out", index))
+        t, r, c = C.c_int32(ovx.VX_TYPE_FLOAT32), C.c_size_t(1), C.c_size_t(3)
+        L.vxSetMetaFormatAttribute(meta, ovx.VX_MATRIX_TYPE, C.byref(t), 4)
+        L.vxSetMetaFormatAttribute(meta, ovx.VX_MATRIX_ROWS, C.byref(r), 8)
+        L.vxSetMetaFormatAttribute(meta, ovx.VX_MATRIX_COLUMNS, C.byref(c), 8)
+        return ovx.VX_SUCCESS
+
+    f, iv, ov = ovx.KERNEL_F(lambda n, p, c: 0), ovx.INPUT_VALIDATE_F(in_validate), ovx.OUTPUT_VALIDATE_F(out_validate)
+    none_f = C.cast(None, ovx.KERNEL_F)
+    _KEEP.extend([f, iv, ov])
+    kid = C.c_int32()
+    assert L.vxAllocateUserKernelId(ctx, C.byref(kid)) == ovx.VX_SUCCESS
+    k = L.vxAddKernel(ctx, b"example.test.scale", kid.value, f, 2, iv, ov, none_f, none_f)
+    assert L.vxGetStatus(k) == ovx.VX_SUCCESS
+    assert L.vxAddParameterToKernel(k, 0, ovx.VX_INPUT, ovx.VX_TYPE_MATRIX, ovx.VX_PARAMETER_STATE_REQUIRED) == 0
+    assert L.vxAddParameterToKernel(k, 1, ovx.VX_OUTPUT, ovx.VX_TYPE_MATRIX, ovx.VX_PARAMETER_STATE_REQUIRED) == 0
+    assert L.vxFinalizeKernel(k) == ovx.VX_SUCCESS
+    g = L.vxCreateGraph(ctx)
+    n = L.vxCreateGenericNode(g, k)
+    a, b = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 1), L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 1)
+    assert L.vxSetParameterByIndex(n, 0, a) == 0 and L.vxSetParameterByIndex(n, 1, b) == 0
+    refs_before = ovx.query("vxQueryReference", a, ovx.VX_REFERENCE_COUNT, C.c_uint32)
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    assert calls == [("in", 0, 1, 3), ("out", 1)]
+    assert ovx.query("vxQueryReference", a, ovx.VX_REFERENCE_COUNT, C.c_uint32) == refs_before
+    assert ovx.query("vxQueryReference", n, ovx.VX_REFERENCE_COUNT, C.c_uint32) == 2       # the parameter object let go of the node
+    assert L.vxSetParameterByIndex(n, 0, L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)) == 0
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_PARAMETERS
+    assert L.vxGetStatus(L.vxGetParameterByIndex(n, 2)) == ovx.VX_ERROR_INVALID_PARAMETERS

@@ -137,11 +137,18 @@ struct _vx_kernel : _vx_reference {
     vx_enum enumeration = 0;
     vx_kernel_f func = nullptr;
     vx_kernel_validate_f validate = nullptr;
+    vx_kernel_input_validate_f in_validate = nullptr;      // OpenVX 1.0 form (vxAddKernel)
+    vx_kernel_output_validate_f out_validate = nullptr;
     vx_kernel_initialize_f init = nullptr;
     vx_kernel_deinitialize_f deinit = nullptr;
     std::vector<ParamSpec> spec;
     std::vector<bool> spec_set;
     bool finalized = false;
+};
+
+struct _vx_parameter : _vx_reference {
+    _vx_node *node = nullptr;      // retained
+    vx_uint32 index = 0;
 };
 
 // what a validator says about one output: attribute -> value bytes, compared with the bound object at vxVerifyGraph
@@ -343,6 +350,11 @@ void destroy(_vx_reference *r)
         if (m->dev) (void)hipFree(m->dev);
         break;
     }
+    case VX_TYPE_PARAMETER: {
+        auto *pr = static_cast<_vx_parameter *>(r);
+        release_ref(pr->node);
+        break;
+    }
     case VX_TYPE_NODE: {
         auto *n = static_cast<_vx_node *>(r);
         if (n->kernel) {
@@ -381,6 +393,7 @@ void destroy(_vx_reference *r)
     case VX_TYPE_NODE: delete static_cast<_vx_node *>(r); break;
     case VX_TYPE_GRAPH: delete static_cast<_vx_graph *>(r); break;
     case VX_TYPE_KERNEL: delete static_cast<_vx_kernel *>(r); break;
+    case VX_TYPE_PARAMETER: delete static_cast<_vx_parameter *>(r); break;
     case VX_TYPE_META_FORMAT: delete static_cast<_vx_meta_format *>(r); break;
     default: delete r; break;
     }
@@ -855,6 +868,11 @@ vx_status verify_user_node(_vx_node *nd)
     }
     vx_status st = VX_SUCCESS;
     if (k->validate) st = k->validate(nd, nd->params.data(), num, metas.data());
+    for (vx_uint32 i = 0; i < num && st == VX_SUCCESS; ++i) {      // OpenVX 1.0 validators: one call per parameter
+        if (!nd->params[i]) continue;                               // an optional parameter left unset
+        if (nd->spec[i].dir == VX_INPUT) { if (k->in_validate) st = k->in_validate(nd, i); }
+        else if (k->out_validate) st = k->out_validate(nd, i, metas[i]);
+    }
     if (st != VX_SUCCESS) {
         std::string msg = "vxVerifyGraph: the validator of user kernel '" + k->name + "' rejected its parameters";
         log_msg(ctx, nd, st, msg.c_str());
@@ -1331,7 +1349,7 @@ vx_status vxReleaseContext(vx_context *context)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     // tear down whatever the application left behind: graphs first, then containers, then leaves
     ctx->kernels.clear();
-    static const vx_enum order[] = { VX_TYPE_GRAPH, VX_TYPE_NODE, VX_TYPE_KERNEL, VX_TYPE_DELAY, VX_TYPE_PYRAMID, VX_TYPE_IMAGE,
+    static const vx_enum order[] = { VX_TYPE_PARAMETER, VX_TYPE_GRAPH, VX_TYPE_NODE, VX_TYPE_KERNEL, VX_TYPE_DELAY, VX_TYPE_PYRAMID, VX_TYPE_IMAGE,
                                      VX_TYPE_ARRAY, VX_TYPE_MATRIX, VX_TYPE_SCALAR };
     for (vx_enum t : order) {
         for (;;) {
@@ -2091,6 +2109,51 @@ vx_kernel vxAddUserKernel(vx_context context, const vx_char name[VX_MAX_KERNEL_N
     track(context, k);
     return k;
 }
+
+vx_kernel vxAddKernel(vx_context context, const vx_char name[VX_MAX_KERNEL_NAME], vx_enum enumeration, vx_kernel_f func_ptr,
+                      vx_uint32 numParams, vx_kernel_input_validate_f input, vx_kernel_output_validate_f output,
+                      vx_kernel_initialize_f init, vx_kernel_deinitialize_f deinit)
+{
+    vx_kernel k = vxAddUserKernel(context, name, enumeration, func_ptr, numParams, nullptr, init, deinit);
+    if (valid(k, VX_TYPE_KERNEL)) { k->in_validate = input; k->out_validate = output; }
+    return k;
+}
+
+vx_parameter vxGetParameterByIndex(vx_node node, vx_uint32 index)
+{
+    auto *n = as<_vx_node>(node, VX_TYPE_NODE);
+    if (!n) return nullptr;
+    if (index >= n->params.size()) return make_error<vx_parameter>(n->ctx, VX_ERROR_INVALID_PARAMETERS, "vxGetParameterByIndex: no such parameter");
+    auto *p = new _vx_parameter();
+    p->type = VX_TYPE_PARAMETER;
+    p->ctx = n->ctx;
+    p->node = n;
+    p->index = index;
+    retain(n);
+    track(n->ctx, p);
+    return p;
+}
+
+vx_status vxQueryParameter(vx_parameter param, vx_enum attribute, void *ptr, vx_size size)
+{
+    auto *p = as<_vx_parameter>(param, VX_TYPE_PARAMETER);
+    if (!p || !valid(p->node, VX_TYPE_NODE)) return VX_ERROR_INVALID_REFERENCE;
+    const ParamSpec &sp = p->node->spec[p->index];
+    switch (attribute) {
+    case VX_PARAMETER_INDEX: return query_out(ptr, size, &p->index, sizeof(vx_uint32));
+    case VX_PARAMETER_DIRECTION: return query_out(ptr, size, &sp.dir, sizeof(vx_enum));
+    case VX_PARAMETER_TYPE: return query_out(ptr, size, &sp.type, sizeof(vx_enum));
+    case VX_PARAMETER_STATE: { vx_enum v = sp.optional ? VX_PARAMETER_STATE_OPTIONAL : VX_PARAMETER_STATE_REQUIRED; return query_out(ptr, size, &v, sizeof(v)); }
+    case VX_PARAMETER_REF: {
+        _vx_reference *r = p->node->params[p->index];
+        retain(r);                                     // the caller releases it (SfM.cpp:1233)
+        return query_out(ptr, size, &r, sizeof(r));
+    }
+    default: return VX_ERROR_NOT_SUPPORTED;
+    }
+}
+
+vx_status vxReleaseParameter(vx_parameter *param) { return release_handle(param, VX_TYPE_PARAMETER); }
 
 vx_status vxAddParameterToKernel(vx_kernel kernel, vx_uint32 index, vx_enum dir, vx_enum data_type, vx_enum state)
 {

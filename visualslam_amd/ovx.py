@@ -78,6 +78,9 @@ LOG_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int32, C.c_char_p)
 # user-kernel callbacks (VX/vx.h): func / init / deinit (node, parameters, num); validate (node, parameters, num, metas)
 KERNEL_F = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32)
 VALIDATE_F = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_void_p))
+INPUT_VALIDATE_F = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32)                  # OpenVX 1.0 (vxAddKernel)
+OUTPUT_VALIDATE_F = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_uint32, C.c_void_p)
+VX_PARAMETER_INDEX, VX_PARAMETER_DIRECTION, VX_PARAMETER_TYPE, VX_PARAMETER_STATE, VX_PARAMETER_REF = range(0x80500, 0x80505)
 
 _SIGS = {
     "vxCreateContext": (C.c_void_p, []),
@@ -165,6 +168,10 @@ _SIGS = {
     "vxuWarpPerspective": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "vxAllocateUserKernelId": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "vxAddUserKernel": (C.c_void_p, [C.c_void_p, C.c_char_p, C.c_int32, KERNEL_F, C.c_uint32, VALIDATE_F, KERNEL_F, KERNEL_F]),
+    "vxAddKernel": (C.c_void_p, [C.c_void_p, C.c_char_p, C.c_int32, KERNEL_F, C.c_uint32, INPUT_VALIDATE_F, OUTPUT_VALIDATE_F, KERNEL_F, KERNEL_F]),
+    "vxGetParameterByIndex": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "vxQueryParameter": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "vxReleaseParameter": (C.c_int32, [C.POINTER(C.c_void_p)]),
     "vxAddParameterToKernel": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32]),
     "vxFinalizeKernel": (C.c_int32, [C.c_void_p]),
     "vxRemoveKernel": (C.c_int32, [C.c_void_p]),
