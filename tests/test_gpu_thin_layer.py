@@ -160,13 +160,14 @@ def test_harris_track_mask_and_tracked_merge(gpu):
 
 
 def test_harris_track_many_tracked_points_and_cells(gpu):
-    """chunks beyond the merge kernel's register path: > 8192 tracked points and > 8192 cells"""
+    """chunks beyond the merge kernel's register path: > 8192 tracked points and > 8192 cells; at cell size 2 the grid
+    (76800 cells) is also beyond the LDS flags, so occupied cells are marked in the keys themselves"""
     w, h = 640, 480
     gray = _scene(w, h, seed=21)
     rng = np.random.default_rng(5)
     tracked = np.stack([rng.uniform(-3, w + 3, 9000), rng.uniform(-3, h + 3, 9000)], 1).astype(np.float32)
     tracked[::5] = (-1.0, -1.0)
-    for cell, cap in ((4, 12000), (18, 9500)):
+    for cell, cap in ((4, 12000), (18, 9500), (2, 20000)):
         got, gtot = _run_track("harris", gray, None, tracked, nvxcu.NVXCU_TYPE_POINT2F, cell, cap, k=0.04, threshold=100.0)
         want, wtot, _ = O.harris_track(gray, None, tracked, 0.04, 100.0, cell, cap, item_type=O.POINT2F)
         assert gtot == wtot

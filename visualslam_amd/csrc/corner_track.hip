@@ -60,11 +60,15 @@ __device__ __forceinline__ float harris_r(int a, int b, int c, float k)
     return det - k * tr * tr;
 }
 
-// FAST-N: -inf unless the pixel is a corner at threshold t; then the exact strength (largest
-// threshold for which it still is one).  Pixels below t cannot beat a candidate in the NMS, so
-// their exact strength is never needed.
-__device__ __forceinline__ float fast_score(const uint8_t *c /* centre in LDS */, int n, int t)
+// FAST-N strength: the largest threshold for which the pixel still passes the segment test, i.e.
+// max over the 16 arcs of N consecutive circle pixels of min(d) (brighter) or min(-d) (darker), minus one; -inf when
+// no arc is uniformly brighter or darker (strength < 0).  Branch-free: arcs are built from 3-pixel minima/maxima
+// (v_min3 / v_max3), every lane does the same ~90 integer operations, so a wave's cost does not depend on whether
+// one of its 64 pixels happens to be a corner.
+template <int N>
+__device__ __forceinline__ float fast_score(const uint8_t *c /* centre in LDS */)
 {
+    static_assert(N >= 9 && N <= 12, "FAST-9 .. FAST-12");
     const int ip = c[0];
     int d[16];
     d[0]  = c[-3 * PXW + 0] - ip;  d[1]  = c[-3 * PXW + 1] - ip;
@@ -75,35 +79,25 @@ __device__ __forceinline__ float fast_score(const uint8_t *c /* centre in LDS */
     d[10] = c[2 * PXW - 2] - ip;   d[11] = c[1 * PXW - 3] - ip;
     d[12] = c[-3] - ip;            d[13] = c[-1 * PXW - 3] - ip;
     d[14] = c[-2 * PXW - 2] - ip;  d[15] = c[-3 * PXW - 1] - ip;
-    uint32_t mb = 0, md = 0;
+    int lo3[16], hi3[16];          // min / max of circle pixels i, i+1, i+2
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        mb |= (d[i] > t ? 1u : 0u) << i;
-        md |= (d[i] < -t ? 1u : 0u) << i;
+        lo3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+        hi3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
     }
-    mb |= mb << 16;
-    md |= md << 16;
-    uint32_t rb = mb, rd = md;
-    for (int i = 1; i < n; ++i) {
-        rb &= mb >> i;
-        rd &= md >> i;
-    }
-    if (((rb | rd) & 0xffffu) == 0) return -INFINITY;
-    int best = 0;
+    int bright = -256, dark = 256;  // max over arcs of min(d); min over arcs of max(d)
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        int lo = 255, hi = 255;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            if (i < n) {
-                const int v = d[(s + i) & 15];
-                lo = min(lo, v);
-                hi = min(hi, -v);
-            }
-        }
-        best = max(best, max(lo, hi));
+    for (int i = 0; i < 16; ++i) {
+        int lo = min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]);     // 9 consecutive pixels from i
+        int hi = max(max(hi3[i], hi3[(i + 3) & 15]), hi3[(i + 6) & 15]);
+        if (N == 10) { lo = min(lo, d[(i + 9) & 15]); hi = max(hi, d[(i + 9) & 15]); }
+        if (N == 11) { lo = min(min(lo, d[(i + 9) & 15]), d[(i + 10) & 15]); hi = max(max(hi, d[(i + 9) & 15]), d[(i + 10) & 15]); }
+        if (N == 12) { lo = min(lo, lo3[(i + 9) & 15]); hi = max(hi, hi3[(i + 9) & 15]); }
+        bright = max(bright, lo);
+        dark = min(dark, hi);
     }
-    return (float)(best - 1);
+    const int best = max(max(bright, -dark), 0);
+    return best > 0 ? (float)(best - 1) : -INFINITY;
 }
 
 // ---- Harris: one wave per rectangle of cells, lane = column ----------------------------------
@@ -192,7 +186,7 @@ __device__ __forceinline__ void harris_emit(const CornerArgs &a, const HarrisTil
     const int gy = t.gy_tile0 + 3 + n;
     if (a.mask && a.mask[(size_t)gy * a.mask_pitch + t.gx] == 0) return;
     const int cell = ((t.cell_row0 + n) / a.cs) * a.nbx + t.cell_x;
-    const uint32_t idx = (uint32_t)gy * (uint32_t)a.w + (uint32_t)t.gx;
+    const uint32_t idx = ((uint32_t)gy << 16) | (uint32_t)t.gx;     // raster order for images up to 65535 x 65535, decoded by shifts
     const uint64_t key = ((uint64_t)orderable(c) << 32) | (uint64_t)(~idx);
     atomicMax(reinterpret_cast<unsigned long long *>(&t.keys[cell]), (unsigned long long)key);
 }
@@ -299,6 +293,7 @@ __global__ __launch_bounds__(64) void k_harris_cells(CornerArgs a)
 }
 
 // ---- FAST: 256-thread workgroup over LDS-staged tiles ------------------------------------------
+template <int N>
 __global__ __launch_bounds__(256) void k_fast_cells(CornerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -341,7 +336,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(CornerArgs a)
                     const int gx = gx0 - 1 + c, gy = gy0 - 1 + r;
                     float s = -INFINITY;
                     if (gx >= 3 && gy >= 3 && gx < a.w - 3 && gy < a.h - 3)
-                        s = fast_score(px + (r + HALO - 1) * PXW + (c + HALO - 1), a.fast_n, a.fast_t);
+                        s = fast_score<N>(px + (r + HALO - 1) * PXW + (c + HALO - 1));
                     sc[i] = s;
                 }
             }
@@ -366,7 +361,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(CornerArgs a)
                     const int gx = gx0 + lx, gy = gy0 + ly;
                     if (a.mask && a.mask[(size_t)gy * a.mask_pitch + gx] == 0) continue;
                     const int cell = ((ty + ly) / a.cs) * a.nbx + (tx + lx) / a.cs;
-                    const uint32_t idx = (uint32_t)gy * (uint32_t)a.w + (uint32_t)gx;
+                    const uint32_t idx = ((uint32_t)gy << 16) | (uint32_t)gx;
                     const uint64_t key = ((uint64_t)orderable(s) << 32) | (uint64_t)(~idx);
                     atomicMax(reinterpret_cast<unsigned long long *>(&keys[cell]), (unsigned long long)key);
                 }
@@ -394,6 +389,8 @@ struct MergeArgs {
     uint64_t *num_corners_host;
     uint64_t *cell_best;
     int w, h, cs, ncx, ncy;
+    uint32_t cs_magic;              // ceil(2^32 / cs): x / cs == umulhi(x, cs_magic) for x < 65536 (cs > 1)
+    uint32_t flag_words;            // > 0: occupied cells are marked in LDS, one byte a cell, this many 32-bit words
 };
 
 struct KeypointF {
@@ -402,21 +399,74 @@ struct KeypointF {
     float error;
 };
 
-__device__ __forceinline__ bool tracked_alive(const MergeArgs &a, uint32_t i, float &x, float &y)
+#ifdef VSA_MG_STAMPS   // development instrumentation: cycle stamps of the merge kernel's phases (thread 0)
+__device__ uint64_t g_mg_stamps[16];
+#define MG_STAMP(i) do { if (threadIdx.x == 0) g_mg_stamps[i] = clock64(); } while (0)
+#else
+#define MG_STAMP(i) do { } while (0)
+#endif
+
+constexpr uint32_t MG_THREADS = 1024, MG_WAVES = MG_THREADS / 64;
+// rounds of 64 items per wave whose data stays in registers: 8 + 8 (8192 points, 8192 cells: 1080p / cell 18 has 6420
+// cells); larger arrays (4K / cell 18 has 25680 cells) walk in blocks of 12 rounds of points and 26 of cells
+constexpr uint32_t MG_K1 = 8, MG_KT2 = 12, MG_KC2 = 26;
+
+// Every fetch below is unconditional, from an index clamped into the array, and the validity test follows once the
+// whole block of loads is out: a load inside a branch (or a select fed by one) makes the compiler wait for it where
+// the branch joins, which strings a block's loads into one memory round trip each.
+//
+// N rounds of tracked points starting at item `first` (lane = item); bit r of the result: point r is there
+// (below `nt`, round below `rounds`), tracked, and inside the image.
+template <uint32_t N>
+__device__ __forceinline__ uint32_t tracked_fetch(const MergeArgs &a, uint32_t first, uint32_t round0, uint32_t rounds,
+                                                  uint32_t nt, float (&x)[N], float (&y)[N])
 {
+    const uint32_t last = a.tracked_capacity - 1u;      // callers: capacity > 0
+    int32_t st[N];
     if (a.item == kPoint2f) {
-        const float2 p = reinterpret_cast<const float2 *>(a.tracked)[i];
-        x = p.x; y = p.y;
+#pragma unroll
+        for (uint32_t r = 0; r < N; ++r) {
+            const float2 p = reinterpret_cast<const float2 *>(a.tracked)[min(first + r * 64u, last)];
+            x[r] = p.x; y[r] = p.y; st[r] = 1;
+        }
     } else {
-        const KeypointF *p = reinterpret_cast<const KeypointF *>(a.tracked) + i;
-        x = p->x; y = p->y;
-        if (p->tracking_status == 0) return false;
+#pragma unroll
+        for (uint32_t r = 0; r < N; ++r) {
+            const KeypointF *p = reinterpret_cast<const KeypointF *>(a.tracked) + min(first + r * 64u, last);
+            x[r] = p->x; y[r] = p->y; st[r] = p->tracking_status;
+        }
     }
-    return x >= 0.0f && y >= 0.0f && x <= (float)(a.w - 1) && y <= (float)(a.h - 1);
+    const float xmax = (float)(a.w - 1), ymax = (float)(a.h - 1);
+    uint32_t bits = 0;
+#pragma unroll
+    for (uint32_t r = 0; r < N; ++r) {
+        const bool alive = round0 + r < rounds && first + r * 64u < nt && st[r] != 0 &&
+                           x[r] >= 0.0f && y[r] >= 0.0f && x[r] <= xmax && y[r] <= ymax;
+        bits |= (alive ? 1u : 0u) << r;
+    }
+    return bits;
 }
 
-constexpr uint32_t MG_THREADS = 1024;
-constexpr uint32_t MG_B = 8;   // items a thread keeps in registers (fast path: chunks of at most MG_B points and cells)
+// N rounds of cell keys starting at cell `first`; cells that are not there read as empty
+template <uint32_t N>
+__device__ __forceinline__ void keys_fetch(const MergeArgs &a, uint32_t first, uint32_t round0, uint32_t rounds,
+                                           uint32_t ncells, uint64_t (&k)[N])
+{
+#pragma unroll
+    for (uint32_t r = 0; r < N; ++r) k[r] = a.cell_best[min(first + r * 64u, ncells - 1u)];
+#pragma unroll
+    for (uint32_t r = 0; r < N; ++r) k[r] = (round0 + r < rounds && first + r * 64u < ncells) ? k[r] : 0ull;
+}
+
+__device__ __forceinline__ uint32_t cell_of(const MergeArgs &a, float x, float y)
+{
+    // x, y lie inside an image of at most 65535 x 65535: with m = ceil(2^32 / cs) = (2^32 + e) / cs, e < cs < 2^16,
+    // x * m / 2^32 = x / cs + x * e / (cs * 2^32) and the excess stays below 1 / cs, so the floor is that of x / cs
+    const uint32_t ux = (uint32_t)x, uy = (uint32_t)y;
+    const uint32_t cx = min(a.cs == 1 ? ux : __umulhi(ux, a.cs_magic), (uint32_t)a.ncx - 1u);
+    const uint32_t cy = min(a.cs == 1 ? uy : __umulhi(uy, a.cs_magic), (uint32_t)a.ncy - 1u);
+    return cy * (uint32_t)a.ncx + cx;
+}
 
 __device__ __forceinline__ void emit_survivor(const MergeArgs &a, uint32_t pos, uint32_t i, float x, float y)
 {
@@ -429,7 +479,7 @@ __device__ __forceinline__ void emit_corner(const MergeArgs &a, uint32_t pos, ui
 {
     if (pos >= a.out_capacity) return;
     const uint32_t idx = ~(uint32_t)(key & 0xffffffffull);
-    const float fx = (float)(idx % (uint32_t)a.w), fy = (float)(idx / (uint32_t)a.w);
+    const float fx = (float)(idx & 0xffffu), fy = (float)(idx >> 16);
     if (a.item == kPoint2f) {
         reinterpret_cast<float2 *>(a.out)[pos] = make_float2(fx, fy);
     } else {
@@ -443,109 +493,157 @@ __device__ __forceinline__ void emit_corner(const MergeArgs &a, uint32_t pos, ui
     }
 }
 
-// One pass, one block-wide scan: thread t owns the t-th contiguous chunk of the tracked points and of the
-// cells, so positions follow input order / cell raster order.  The per-thread counts of both lists travel
-// through the scan as the two halves of one 64-bit word.  REG: chunks fit MG_B items, which then stay in
-// registers (all loads of a phase in flight together, nothing re-read).
-template <bool REG>
+// One workgroup, one pass.  Wave w owns the w-th contiguous range of the tracked points and of the cells and walks
+// it in rounds of 64 consecutive items (lane = item: coalesced loads), so positions follow input order / cell raster
+// order: within a round by the ballot's prefix count, across rounds by a running count, across waves by the wave
+// totals (both lists' totals travel as the two halves of one 64-bit word).  KEEP: every range fits KT / KC rounds,
+// so what was loaded stays in registers for the write-out; otherwise the write-out re-reads (L2 hits).
+__device__ __forceinline__ uint32_t lanes_below(uint64_t ballot)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
+
+// KT / KC: rounds of tracked points / cells a wave keeps in registers (KEEP), or the block size of the walks
+template <bool KEEP, uint32_t KT, uint32_t KC>
 __global__ __launch_bounds__(MG_THREADS) void k_merge_compact(MergeArgs a)
 {
-    __shared__ uint64_t wave_tot[MG_THREADS / 64];
+    __shared__ uint64_t wave_tot[MG_WAVES];
+    extern __shared__ uint32_t occ_words[];  // one byte per cell: holds a surviving tracked point
+    uint8_t *occ = reinterpret_cast<uint8_t *>(occ_words);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t nt = a.tracked ? min(*a.tracked_count, a.tracked_capacity) : 0u;
+    MG_STAMP(0);
+    // Cells holding a surviving tracked point are marked in LDS, one byte a cell (plain stores: tracked points arrive
+    // in cell order, so bits would have the lanes of a wave serialize on the same word with atomic ORs); the keys stay
+    // untouched.  Only a cell grid too large for LDS is marked in place, in the keys themselves.
+    const bool in_lds = KEEP || a.flag_words != 0u;
+    for (uint32_t i = tid; i < max(a.flag_words, 1u); i += MG_THREADS) occ_words[i] = 0u;   // word 0 is always there
+    const bool has_t = a.tracked != nullptr && a.tracked_capacity != 0u;
+    const uint32_t cap_t = has_t ? a.tracked_capacity : 0u;
+    // the live count through a vector load (an index the compiler cannot see is zero): as a scalar load it would
+    // have to land before the first vector load issues, one more memory round trip at the head of the kernel
+    uint32_t zero = 0u;
+    asm volatile("" : "+v"(zero));
+    const uint32_t nt = has_t ? min(a.tracked_count[zero], cap_t) : 0u;
     const uint32_t ncells = (uint32_t)a.ncx * (uint32_t)a.ncy;
-    const uint32_t cap_t = a.tracked ? a.tracked_capacity : 0u;
-    // chunk sizes come from the capacity, not the live count, so the register path is a launch-time decision
-    const uint32_t per_t = (cap_t + MG_THREADS - 1) / MG_THREADS, per_c = (ncells + MG_THREADS - 1) / MG_THREADS;
-    const uint32_t t0 = min(tid * per_t, nt), t1 = min(t0 + per_t, nt);
-    const uint32_t c0 = min(tid * per_c, ncells), c1 = min(c0 + per_c, ncells);
+    // range sizes come from the capacity, not the live count, so KEEP is a launch-time decision
+    const uint32_t rounds_t = (cap_t + MG_THREADS - 1) / MG_THREADS, rounds_c = (ncells + MG_THREADS - 1) / MG_THREADS;
+    const uint32_t tbase = wave * rounds_t * 64u + lane, cbase = wave * rounds_c * 64u + lane;
 
     // phase 0: cells holding a surviving tracked point emit no new corner
-    uint32_t n_alive = 0;
-    float px[MG_B], py[MG_B];
-    bool alive[MG_B];
-    if (REG) {
+    uint32_t n_alive = 0, alive_bits = 0;
+    float px[KEEP ? KT : 1], py[KEEP ? KT : 1];
+    uint64_t key[KEEP ? KC : 1];
+    if constexpr (KEEP) {
+        keys_fetch<KC>(a, cbase, 0u, rounds_c, ncells, key);    // in flight together with the points
+        if (has_t) alive_bits = tracked_fetch<KT>(a, tbase, 0u, rounds_t, nt, px, py);
+        __syncthreads();      // flags cleared
+        MG_STAMP(1);
 #pragma unroll
-        for (uint32_t j = 0; j < MG_B; ++j) {
-            const uint32_t i = t0 + j;
-            px[j] = 0.0f; py[j] = 0.0f;
-            alive[j] = (i < t1) && tracked_alive(a, i, px[j], py[j]);
+        for (uint32_t r = 0; r < KT; ++r) {
+            const bool alive = (alive_bits >> r) & 1u;
+            if (alive) occ[cell_of(a, px[r], py[r])] = 1;
+            n_alive += (uint32_t)__popcll(__ballot(alive));
         }
+    } else {   // blocks of KT rounds: the loads of a block are in flight together
+        __syncthreads();      // flags cleared
+        MG_STAMP(1);
+        for (uint32_t r0 = 0; has_t && r0 < rounds_t; r0 += KT) {
+            float x[KT], y[KT];
+            const uint32_t bits = tracked_fetch<KT>(a, tbase + r0 * 64u, r0, rounds_t, nt, x, y);
 #pragma unroll
-        for (uint32_t j = 0; j < MG_B; ++j)
-            if (alive[j]) {
-                ++n_alive;
-                const uint32_t cx = min((uint32_t)px[j] / (uint32_t)a.cs, (uint32_t)a.ncx - 1u);
-                const uint32_t cy = min((uint32_t)py[j] / (uint32_t)a.cs, (uint32_t)a.ncy - 1u);
-                a.cell_best[(size_t)cy * a.ncx + cx] = OCCUPIED;
-            }
-    } else {
-        for (uint32_t i = t0; i < t1; ++i) {
-            float x, y;
-            if (tracked_alive(a, i, x, y)) {
-                ++n_alive;
-                const uint32_t cx = min((uint32_t)x / (uint32_t)a.cs, (uint32_t)a.ncx - 1u);
-                const uint32_t cy = min((uint32_t)y / (uint32_t)a.cs, (uint32_t)a.ncy - 1u);
-                a.cell_best[(size_t)cy * a.ncx + cx] = OCCUPIED;
+            for (uint32_t r = 0; r < KT; ++r) {
+                const bool alive = (bits >> r) & 1u;
+                if (alive) {
+                    const uint32_t cell = cell_of(a, x[r], y[r]);
+                    if (in_lds) occ[cell] = 1;
+                    else a.cell_best[cell] = OCCUPIED;
+                }
+                n_alive += (uint32_t)__popcll(__ballot(alive));
             }
         }
     }
-    __threadfence_block();
+    MG_STAMP(2);
+    if (!in_lds) __threadfence_block();
     __syncthreads();
+    MG_STAMP(3);
 
+    // a cell emits its corner when it has one and holds no surviving tracked point
+    auto fresh_key = [&](uint64_t k, uint32_t c) {
+        // no short circuit: a flag read behind a branch would make every round wait for its own LDS round trip
+        const uint32_t marked = occ[in_lds ? min(c, ncells - 1u) : 0u];
+        return (k != 0ull) & (k != OCCUPIED) & (marked == 0u);
+    };
     uint32_t n_new = 0;
-    uint64_t key[MG_B];
-    if (REG) {
+    if constexpr (KEEP) {
 #pragma unroll
-        for (uint32_t j = 0; j < MG_B; ++j) key[j] = (c0 + j < c1) ? a.cell_best[c0 + j] : 0ull;
-#pragma unroll
-        for (uint32_t j = 0; j < MG_B; ++j) n_new += (key[j] != 0ull && key[j] != OCCUPIED) ? 1u : 0u;
+        for (uint32_t r = 0; r < KC; ++r) n_new += (uint32_t)__popcll(__ballot(fresh_key(key[r], cbase + r * 64u)));
     } else {
-        for (uint32_t c = c0; c < c1; ++c) {
-            const uint64_t k = a.cell_best[c];
-            n_new += (k != 0ull && k != OCCUPIED) ? 1u : 0u;
+        for (uint32_t r0 = 0; r0 < rounds_c; r0 += KC) {
+            uint64_t k[KC];
+            keys_fetch<KC>(a, cbase + r0 * 64u, r0, rounds_c, ncells, k);
+#pragma unroll
+            for (uint32_t r = 0; r < KC; ++r) n_new += (uint32_t)__popcll(__ballot(fresh_key(k[r], cbase + (r0 + r) * 64u)));
         }
     }
 
-    // block-wide exclusive scan of (n_alive, n_new)
-    const uint64_t v = (uint64_t)n_alive | ((uint64_t)n_new << 32);
-    uint64_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint64_t u = __shfl_up(incl, off);
-        if ((int)lane >= off) incl += u;
-    }
-    if (lane == 63u) wave_tot[wave] = incl;
+    // the counts are wave-uniform: exclusive scan over the wave totals
+    MG_STAMP(4);
+    if (lane == 0u) wave_tot[wave] = (uint64_t)n_alive | ((uint64_t)n_new << 32);
     __syncthreads();
+    MG_STAMP(5);
     uint64_t wave_off = 0, total = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < MG_THREADS / 64; ++i) {
+    for (uint32_t i = 0; i < MG_WAVES; ++i) {
         const uint64_t t = wave_tot[i];
         wave_off += (i < wave) ? t : 0ull;
         total += t;
     }
-    const uint64_t excl = wave_off + incl - v;
     const uint32_t total_alive = (uint32_t)total, total_new = (uint32_t)(total >> 32);
 
-    uint32_t pos = (uint32_t)excl;                              // survivors, input order
-    uint32_t cpos = total_alive + (uint32_t)(excl >> 32);       // new corners, cell raster order
-    if (REG) {
+    uint32_t pos = (uint32_t)wave_off;                              // survivors, input order
+    uint32_t cpos = total_alive + (uint32_t)(wave_off >> 32);       // new corners, cell raster order
+    if constexpr (KEEP) {
 #pragma unroll
-        for (uint32_t j = 0; j < MG_B; ++j)
-            if (alive[j]) emit_survivor(a, pos++, t0 + j, px[j], py[j]);
-#pragma unroll
-        for (uint32_t j = 0; j < MG_B; ++j)
-            if (key[j] != 0ull && key[j] != OCCUPIED) emit_corner(a, cpos++, key[j]);
-    } else {
-        for (uint32_t i = t0; i < t1; ++i) {
-            float x, y;
-            if (tracked_alive(a, i, x, y)) emit_survivor(a, pos++, i, x, y);
+        for (uint32_t r = 0; r < KT; ++r) {
+            const bool alive = (alive_bits >> r) & 1u;
+            const uint64_t b = __ballot(alive);
+            if (alive) emit_survivor(a, pos + lanes_below(b), tbase + r * 64u, px[r], py[r]);
+            pos += (uint32_t)__popcll(b);
         }
-        for (uint32_t c = c0; c < c1; ++c) {
-            const uint64_t k = a.cell_best[c];
-            if (k != 0ull && k != OCCUPIED) emit_corner(a, cpos++, k);
+        MG_STAMP(7);
+#pragma unroll
+        for (uint32_t r = 0; r < KC; ++r) {
+            const bool fresh = fresh_key(key[r], cbase + r * 64u);
+            const uint64_t b = __ballot(fresh);
+            if (fresh) emit_corner(a, cpos + lanes_below(b), key[r]);
+            cpos += (uint32_t)__popcll(b);
+        }
+    } else {
+        for (uint32_t r0 = 0; has_t && r0 < rounds_t; r0 += KT) {
+            float x[KT], y[KT];
+            const uint32_t bits = tracked_fetch<KT>(a, tbase + r0 * 64u, r0, rounds_t, nt, x, y);
+#pragma unroll
+            for (uint32_t r = 0; r < KT; ++r) {
+                const bool alive = (bits >> r) & 1u;
+                const uint64_t b = __ballot(alive);
+                if (alive) emit_survivor(a, pos + lanes_below(b), tbase + (r0 + r) * 64u, x[r], y[r]);
+                pos += (uint32_t)__popcll(b);
+            }
+        }
+        MG_STAMP(7);
+        for (uint32_t r0 = 0; r0 < rounds_c; r0 += KC) {
+            uint64_t k[KC];
+            keys_fetch<KC>(a, cbase + r0 * 64u, r0, rounds_c, ncells, k);
+#pragma unroll
+            for (uint32_t r = 0; r < KC; ++r) {
+                const bool fresh = fresh_key(k[r], cbase + (r0 + r) * 64u);
+                const uint64_t b = __ballot(fresh);
+                if (fresh) emit_corner(a, cpos + lanes_below(b), k[r]);
+                cpos += (uint32_t)__popcll(b);
+            }
         }
     }
+    MG_STAMP(6);
     if (tid == 0) {
         const uint32_t base = total_alive + total_new;
         *a.out_count = min(base, a.out_capacity);
@@ -575,6 +673,7 @@ size_t corner_track_scratch_bytes(uint32_t width, uint32_t height, uint32_t cell
 hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
 {
     const uint32_t cs = p.cell_size;
+    if (p.image.width > 65535u || p.image.height > 65535u) return hipErrorInvalidValue;   // cell keys hold (y << 16) | x
     CornerArgs a{};
     a.img = p.image.ptr; a.pitch = p.image.pitch; a.w = (int)p.image.width; a.h = (int)p.image.height;
     a.mask = p.mask; a.mask_pitch = p.mask_pitch;
@@ -594,7 +693,13 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
         hipLaunchKernelGGL(k_harris_cells, dim3(grid.x * grid.y), dim3(64), lds, stream, a);
     } else {
         const size_t lds = keys_b + SW * SH * 4 + PXW * PXH;
-        hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), lds, stream, a);
+        switch (p.fast_n) {
+        case 9: hipLaunchKernelGGL(k_fast_cells<9>, grid, dim3(256), lds, stream, a); break;
+        case 10: hipLaunchKernelGGL(k_fast_cells<10>, grid, dim3(256), lds, stream, a); break;
+        case 11: hipLaunchKernelGGL(k_fast_cells<11>, grid, dim3(256), lds, stream, a); break;
+        case 12: hipLaunchKernelGGL(k_fast_cells<12>, grid, dim3(256), lds, stream, a); break;
+        default: return hipErrorInvalidValue;
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -607,11 +712,24 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
     m.out_count_host = p.out_count_host; m.num_corners_host = p.num_corners_host;
     m.w = a.w; m.h = a.h; m.cs = a.cs; m.ncx = a.ncx; m.ncy = a.ncy;
     const uint32_t ncells = (uint32_t)a.ncx * (uint32_t)a.ncy;
-    const bool reg = (p.tracked ? p.tracked_capacity : 0u) <= MG_B * MG_THREADS && ncells <= MG_B * MG_THREADS;
-    if (reg) hipLaunchKernelGGL(k_merge_compact<true>, dim3(1), dim3(MG_THREADS), 0, stream, m);
-    else hipLaunchKernelGGL(k_merge_compact<false>, dim3(1), dim3(MG_THREADS), 0, stream, m);
+    if (ncells == 0u) return hipErrorInvalidValue;
+    const uint32_t cap_t = p.tracked ? p.tracked_capacity : 0u;
+    m.flag_words = ncells <= 60u * 1024u ? (ncells + 3u) / 4u : 0u;   // beyond 60 K cells the keys are marked in place
+    const size_t lds = (size_t)(m.flag_words ? m.flag_words : 1u) * 4u;
+    m.cs_magic = cs > 1u ? (uint32_t)((0x100000000ull + cs - 1u) / cs) : 0u;
+    if (cap_t <= MG_K1 * MG_THREADS && ncells <= MG_K1 * MG_THREADS)
+        hipLaunchKernelGGL((k_merge_compact<true, MG_K1, MG_K1>), dim3(1), dim3(MG_THREADS), lds, stream, m);
+    else
+        hipLaunchKernelGGL((k_merge_compact<false, MG_KT2, MG_KC2>), dim3(1), dim3(MG_THREADS), lds, stream, m);
     return hipGetLastError();
 }
 
 }  // namespace vsa
+
+#ifdef VSA_MG_STAMPS
+extern "C" int visualslam_amd_debug_mg_stamps(uint64_t *host, size_t n_u64)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vsa::g_mg_stamps), n_u64 * sizeof(uint64_t));
+}
+#endif
 
