@@ -73,30 +73,46 @@ struct PyrFusedArgs {
     int aligned;    // src base and pitch are multiples of 4
 };
 
+constexpr int pyr_pow2_at_least(int n) { return n <= 1 ? 1 : 2 * pyr_pow2_at_least((n + 1) / 2); }
+
+// A thread keeps one destination column for the whole step (CW = RD rounded up to a power of two columns per row of
+// threads, so row and column are a shift and a mask of the thread index and everything that depends on the column
+// only -- the replicate clamp, the source offset, the ownership test -- is computed once); rows advance by a fixed
+// stride.  Per output that leaves the five LDS reads, four multiply-adds and the store.
 template <int RS, int SS, int RD>
 __device__ __forceinline__ void pyr_step(const uint8_t *src, int soff, int sox, int soy,
                                          uint8_t *dstl, int dox, int doy, int dw, int dh,
                                          uint16_t *tmp, uint8_t *gdst, uint32_t gpitch,
                                          int own_x0, int own_y0, int own_n, int tid)
 {
+    constexpr int CW = pyr_pow2_at_least(RD) < PYR_THREADS ? pyr_pow2_at_least(RD) : PYR_THREADS;
+    constexpr int RSTEP = PYR_THREADS / CW;
+    const int c = tid & (CW - 1), r0 = tid / CW;
+    const int X = dox + c;
+    const bool col = c < RD;
     // horizontal: every source-region row, every destination column
-    for (int i = tid; i < RS * RD; i += PYR_THREADS) {
-        const int r = i / RD, c = i % RD;
-        const int xc = min(max(dox + c, 0), dw - 1);
-        const uint8_t *p = src + r * SS + soff + (2 * xc - 2 - sox);
-        tmp[i] = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+    {
+        const int xc = min(max(X, 0), dw - 1);
+        const uint8_t *p = src + r0 * SS + soff + (2 * xc - 2 - sox);
+        uint16_t *t = tmp + r0 * RD + c;
+        if (col)
+            for (int r = r0; r < RS; r += RSTEP, p += RSTEP * SS, t += RSTEP * RD)
+                *t = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
     }
     __syncthreads();
-    for (int i = tid; i < RD * RD; i += PYR_THREADS) {
-        const int y = i / RD, x = i % RD;
-        const int Y = doy + y, X = dox + x;
-        const int yc = min(max(Y, 0), dh - 1);
-        const uint16_t *t = tmp + (2 * yc - 2 - soy) * RD + x;
-        const uint32_t s = t[0] + 4u * t[RD] + 6u * t[2 * RD] + 4u * t[3 * RD] + t[4 * RD];
-        const uint8_t v = (uint8_t)((s + 128u) >> 8);
-        dstl[i] = v;
-        if (X >= own_x0 && X < own_x0 + own_n && Y >= own_y0 && Y < own_y0 + own_n && X < dw && Y < dh)
-            gdst[(size_t)Y * gpitch + X] = v;
+    {
+        const bool own_col = col && X >= own_x0 && X < own_x0 + own_n && X < dw;
+        const int y_end = min(own_y0 + own_n, dh);
+        if (col)
+            for (int y = r0; y < RD; y += RSTEP) {
+                const int Y = doy + y;
+                const int yc = min(max(Y, 0), dh - 1);
+                const uint16_t *t = tmp + (2 * yc - 2 - soy) * RD + c;
+                const uint32_t s = t[0] + 4u * t[RD] + 6u * t[2 * RD] + 4u * t[3 * RD] + t[4 * RD];
+                const uint8_t v = (uint8_t)((s + 128u) >> 8);
+                dstl[y * RD + c] = v;
+                if (own_col && Y >= own_y0 && Y < y_end) gdst[(size_t)Y * gpitch + X] = v;
+            }
     }
     __syncthreads();
 }
