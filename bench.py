@@ -82,6 +82,10 @@ def main():
                     help="ovx: OpenVX graph API (default, the north-star path); thin: nvxcu primitives")
     ap.add_argument("--host-threads", type=int, default=1,
                     help="ovx: 1 = one host thread per camera stream calling vxProcessGraph (default); 0 = one thread scheduling all graphs")
+    ap.add_argument("--driver", choices=["native", "python"], default="native",
+                    help="ovx with host threads: native = the per-frame C API calls are made by C++ threads "
+                         "(visualslam_amd/csrc/stream_driver.cpp), as the reference's C++ application makes them; "
+                         "python = by Python threads through ctypes (they take turns on the interpreter lock)")
     ap.add_argument("--homography", action="store_true",
                     help="BASELINE configs[4]: append nvxFindHomographyNode (batched RANSAC on the PyrLK matches, the video "
                          "stabilizer's arguments) to every stream's graph; a separate workload, never the headline line")
@@ -159,6 +163,19 @@ def main():
             for k in range(k0, k0 + n):
                 trk.track(ring[(ph + 1 + k) % args.ring], None)
 
+        native = None
+        if args.host_threads and args.driver == "native":
+            drv = C.CDLL(os.path.join(os.path.dirname(nvxcu.LIB_PATH), "libvsa_stream_driver.so"))
+            n = len(trackers)
+            arr = lambda xs: (C.c_void_p * len(xs))(*xs)    # noqa: E731
+            drv.vsa_drive_streams.restype = C.c_int
+            drv.vsa_drive_streams.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+            handles = (arr([t.g for t in trackers]), arr([t.cvt for t in trackers]), arr([t.det for t in trackers]),
+                       arr([t.pyr_delay for t in trackers]), arr([t.pts_delay for t in trackers]), arr(ring))
+
+            def native(k0, n_frames):
+                ovx.check(drv.vsa_drive_streams(n, *handles, len(ring), (C.c_int * n)(*phases), k0, n_frames), "vsa_drive_streams")
+
         def lk_launch_ms():
             perf = ovx.query("vxQueryNode", trackers[0].lk, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
             return perf.avg * 1e-6, int(perf.num)
@@ -167,7 +184,8 @@ def main():
             cur = [trk.curr() for trk in trackers]
             return [int((c[:, 0] >= 0).sum()) for c in cur], [len(c) for c in cur]
         api_desc = ("OpenVX graph C API (VX/vx.h): one graph + HIP stream per camera stream, " +
-                    ("one host thread per stream calling vxProcessGraph" if args.host_threads else "one host thread, vxScheduleGraph/vxWaitGraph"))
+                    (("one native host thread per stream calling vxProcessGraph" if native else "one Python thread per stream calling vxProcessGraph")
+                     if args.host_threads else "one host thread, vxScheduleGraph/vxWaitGraph"))
     else:
         from visualslam_amd.devmem import DeviceImage
         from visualslam_amd.thin_tracker import ThinFeatureTracker
@@ -192,7 +210,9 @@ def main():
 
     def run(k0, n):
         """n steps (= n frames on every camera stream of this GPU) starting at frame index k0"""
-        if args.api == "ovx" and args.host_threads:
+        if args.api == "ovx" and native:
+            native(k0, n)
+        elif args.api == "ovx" and args.host_threads:
             import threading
             ths = [threading.Thread(target=run_stream, args=(i, k0, n)) for i in range(len(trackers))]
             for t in ths:

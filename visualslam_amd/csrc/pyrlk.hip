@@ -21,8 +21,9 @@
 //   * the template is resampled at the feature's sub-pixel offset and differentiated (Scharr/32,
 //     separable, constants folded) in one streaming pass; I, Ix, Iy stay in REGISTERS for all iterations;
 //   * pair math is scalar f32 (the packed-f32 VALU forms issue slower than two plain ones on gfx950);
-//   * sums are combined by DPP row reductions + two DPP row broadcasts + one readlane, in the
-//     butterfly order the oracle mirrors; the 2x2 normal equations are solved wave-uniformly.
+//   * sums are combined in the butterfly order the oracle mirrors, two or three sums per butterfly (lanes of
+//     different lane % 4 carry different sums; DPP quad permutes and row rotations, then the gfx950 row swaps
+//     v_permlane16_swap / v_permlane32_swap across rows); the 2x2 normal equations are solved wave-uniformly.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -66,19 +67,56 @@ __device__ __forceinline__ float dpp_mov(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-// Pairwise butterfly (offsets 1,2,4,8,16,32) read out at lane 63.  Within a row of 16 the partner choice
-// of steps 4 and 8 (mirrors) is immaterial because partial sums are already uniform inside each group;
-// rows are combined as (r0+r1)+(r2+r3): row_bcast:15 adds row 0 into row 1 and row 2 into row 3,
-// row_bcast:31 then adds row 1 into row 3 (float addition commutes exactly).  Needs all 64 lanes active.
+// Wave sums.  The summation order is the pairwise butterfly (offsets 1,2,4,8,16,32) the oracle mirrors (ORC_SUM_WAVE64):
+// ((l0+l1)+(l2+l3)) per quad, (q0+q1)+(q2+q3) per row of 16, (r0+r1)+(r2+r3) per wave; float addition commutes exactly, so
+// which partner supplies which operand is immaterial.  DPP and cross-lane instructions issue at half the rate of plain
+// f32 arithmetic on gfx950 (tools/valu_kinds.hip), so several sums share one butterfly: after the first step each value
+// only needs half of the lanes, after the second a quarter.  Lanes with (lane & 1) == 0 carry the first value, odd lanes
+// the second (wave_sum3: lanes with lane & 2 the third); the remaining steps pair lanes of equal lane % 4 -- row
+// rotations by 4 and 8, whose result is in canonical order in lanes 12..15 of each row, then the gfx950 row swaps
+// (v_permlane16_swap / v_permlane32_swap: lane i of row r meets lane i of row r^1, then of row r^2).  tools/wave_sum2_probe.hip
+// checks the scheme bit for bit against separate butterflies on the GPU.  All 64 lanes must be active.
+typedef unsigned lk_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float wave_sum_rows(float z)
+{
+    z += dpp_mov<0x124, 0xf>(z);   // row_ror:4: quad q meets quad q-1 -> (q3+q2) in lanes 12..15, (q1+q0) in lanes 4..7
+    z += dpp_mov<0x128, 0xf>(z);   // row_ror:8: lanes 12..15 now hold (q3+q2)+(q1+q0)
+    lk_v2u s = __builtin_amdgcn_permlane16_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+    z = __uint_as_float(s.x) + __uint_as_float(s.y);   // rows 0,1: r0+r1; rows 2,3: r2+r3
+    s = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+    return __uint_as_float(s.x) + __uint_as_float(s.y);   // (r0+r1)+(r2+r3) in every row
+}
+__device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ void wave_sum2(float a, float b, bool lane_bit0, float &sa, float &sb)
+{
+    a += dpp_mov<0xB1, 0xf>(a);    // quad_perm [1,0,3,2]
+    b += dpp_mov<0xB1, 0xf>(b);
+    float z = lane_bit0 ? b : a;
+    z += dpp_mov<0x4E, 0xf>(z);    // quad_perm [2,3,0,1]: partner of the same parity
+    z = wave_sum_rows(z);
+    sa = lane_value(z, 62);
+    sb = lane_value(z, 63);
+}
+__device__ __forceinline__ void wave_sum3(float a, float b, float c, bool lane_bit0, bool lane_bit1, float &sa, float &sb, float &sc)
+{
+    a += dpp_mov<0xB1, 0xf>(a);
+    b += dpp_mov<0xB1, 0xf>(b);
+    c += dpp_mov<0xB1, 0xf>(c);
+    float z = lane_bit0 ? b : a;
+    z += dpp_mov<0x4E, 0xf>(z);
+    c += dpp_mov<0x4E, 0xf>(c);
+    z = lane_bit1 ? c : z;         // lanes 0,1 of a quad: a, b; lanes 2,3: c
+    z = wave_sum_rows(z);
+    sa = lane_value(z, 60);
+    sb = lane_value(z, 61);
+    sc = lane_value(z, 63);
+}
+// one value alone (calcError)
 __device__ __forceinline__ float wave_sum(float v)
 {
-    v += dpp_mov<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141, 0xf>(v);   // row_half_mirror
-    v += dpp_mov<0x140, 0xf>(v);   // row_mirror
-    v += dpp_mov<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v += dpp_mov<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    v += dpp_mov<0xB1, 0xf>(v);
+    v += dpp_mov<0x4E, 0xf>(v);
+    return lane_value(wave_sum_rows(v), 63);
 }
 
 // ---- tile staging ----------------------------------------------------------------------------
@@ -165,6 +203,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
+    const bool lane_bit0 = lane & 1, lane_bit1 = lane & 2;
 #ifdef VSA_LK_STAMPS
     const uint64_t st_t0 = __builtin_readcyclecounter();
     const uint64_t st_w0 = wall_clock64();
@@ -293,7 +332,8 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
                 v0p = v0; v1p = v1; v2p = v2;
             }
         }
-        const float Gxx = wave_sum(sxx), Gxy = wave_sum(sxy), Gyy = wave_sum(syy);
+        float Gxx, Gxy, Gyy;
+        wave_sum3(sxx, sxy, syy, lane_bit0, lane_bit1, Gxx, Gxy, Gyy);
 
         // next level's template loads fly while this level iterates
         if (L > 0) {
@@ -353,8 +393,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
                     cp = cc;
                 }
             }
-            b1 = wave_sum(b1);
-            b2 = wave_sum(b2);
+            wave_sum2(b1, b2, lane_bit0, b1, b2);
             const float etx = (Gyy * b1 - Gxy * b2) * inv_det;
             const float ety = (Gxx * b2 - Gxy * b1) * inv_det;
             vx += etx; vy += ety;
