@@ -74,8 +74,8 @@ def cpu_baseline(frames_rgbx, params, budget_s=12.0, max_frames=48):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--streams", type=int, default=16, help="camera streams per GPU")
     ap.add_argument("--ring", type=int, default=8, help="pre-generated frames resident in HBM")
     ap.add_argument("--api", choices=["ovx", "thin"], default="ovx",
@@ -267,6 +267,16 @@ def main():
                          "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "launch_ms": lk_ms, "algorithmic_bytes_per_launch": BYTES_LK},
         }
+        vf = os.path.join(ROOT, "profiles", "frame_valu_instructions.json")
+        if os.path.exists(vf) and not args.homography:
+            # what actually bounds the path: vector-instruction issue.  Wave-instructions per frame
+            # from the SQ counters, against the f32 FMA issue rate measured on this GPU -- an extra, not the roofline object
+            with open(vf) as f:
+                v = json.load(f)
+            rate = v["wave_instructions_per_frame"] * fps / 1e9 / world
+            out["valu_issue"] = {"wave_instructions_per_frame": v["wave_instructions_per_frame"], "achieved": rate,
+                                 "peak": v["peak_wave_instructions_per_ns"], "unit": "G wave-instructions/s per GPU",
+                                 "frac": rate / v["peak_wave_instructions_per_ns"]}
         if args.homography:
             perf = ovx.query("vxQueryNode", trackers[0].hg, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
             H, mask = trackers[0].homography()

@@ -87,3 +87,20 @@ def test_no_oracle_in_the_product():
             # comments may cite oracle/vxoracle.c as the semantic reference; code may not use it
             assert "import oracle" not in text and "from oracle" not in text, path
             assert "vxoracle.h" not in text and "libvxoracle" not in text and "orc_" not in text, path
+
+
+def test_stream_driver_library_loads_and_uses_only_the_public_c_api():
+    # the bench's native host threads (visualslam_amd/csrc/stream_driver.cpp): a separate small library that may call
+    # nothing but what include/VX/vx.h declares
+    drv = os.path.join(os.path.dirname(LIB), "libvsa_stream_driver.so")
+    assert os.path.exists(drv), "run __graft_entry__.build() first"
+    out = subprocess.check_output(["nm", "-D", drv], text=True)
+    defined = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert {"vsa_drive_stream", "vsa_drive_streams"} <= defined
+    undefined_vx = {l.split()[-1] for l in out.splitlines() if " U " in l and re.match(r"(vx|nvx)", l.split()[-1])}
+    assert undefined_vx == {"vxSetParameterByIndex", "vxAgeDelay", "vxProcessGraph"}
+    assert undefined_vx <= declared_functions(os.path.join(INC, "VX", "vx.h"))
+    lib = ctypes.CDLL(drv)
+    lib.vsa_drive_streams.restype = ctypes.c_int
+    # argument checking only (no context, no device): null handle arrays are refused
+    assert lib.vsa_drive_streams(1, None, None, None, None, None, None, 1, None, 0, 1) == -10   # VX_ERROR_INVALID_PARAMETERS

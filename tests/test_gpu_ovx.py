@@ -354,3 +354,40 @@ def test_context_device_override(gpu, monkeypatch):
     c = L.vxCreateContext()
     assert c and L.vxGetStatus(c) == ovx.VX_ERROR_INVALID_PARAMETERS          # no such GPU: an error context, not a crash
     assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
+
+
+def test_native_host_threads_drive_streams_like_the_python_loop(ctx):
+    """bench.py's host side (visualslam_amd/csrc/stream_driver.cpp): C++ threads, one per camera stream, making the
+    per-frame calls of feature_tracker.cpp:216-224 on graphs that share the frame objects; every stream must end
+    where the oracle ends after the same frames"""
+    w, h, n_streams, n_frames, ring_len = 320, 240, 3, 5, 4
+    p = Params(pyr_levels=4, lk_win_size=10, array_capacity=600)
+    frames = _frames(w, h, ring_len, seed=21)
+    ring = []
+    for f in frames:
+        img = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+        ovx.write_image(img, f)
+        ring.append(img)
+    phases = [0, 1, 3]
+    trackers = [VxFeatureTracker(ctx, p, w, h, ring[ph], None) for ph in phases]
+    drv = C.CDLL(os.path.join(ROOT, "visualslam_amd", "lib", "libvsa_stream_driver.so"))
+    drv.vsa_drive_streams.restype = C.c_int
+    drv.vsa_drive_streams.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    arr = lambda xs: (C.c_void_p * len(xs))(*xs)    # noqa: E731
+    st = drv.vsa_drive_streams(n_streams, arr([t.g for t in trackers]), arr([t.cvt for t in trackers]), arr([t.det for t in trackers]),
+                               arr([t.pyr_delay for t in trackers]), arr([t.pts_delay for t in trackers]), arr(ring), ring_len,
+                               (C.c_int * n_streams)(*phases), 0, n_frames)
+    assert st == ovx.VX_SUCCESS
+    for trk, ph in zip(trackers, phases):
+        ref = OracleTracker(p)
+        ref.init(frames[ph], None)
+        for k in range(n_frames):
+            old, cur = ref.track(frames[(ph + 1 + k) % ring_len], None)
+        np.testing.assert_array_equal(trk.prev(), old)
+        assert trk.curr().tobytes() == cur.tobytes()
+        np.testing.assert_array_equal(trk.merged(), ref.prev_pts)
+    # a bad handle in one stream is reported, the others still finish
+    st = drv.vsa_drive_streams(2, arr([trackers[0].g, trackers[1].cvt]), arr([t.cvt for t in trackers[:2]]), arr([t.det for t in trackers[:2]]),
+                               arr([t.pyr_delay for t in trackers[:2]]), arr([t.pts_delay for t in trackers[:2]]), arr(ring), ring_len,
+                               (C.c_int * 2)(0, 1), 0, 1)
+    assert st == ovx.VX_ERROR_INVALID_REFERENCE

@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["VISUALSLAM_AMD_LIB"] = os.path.join(ROOT, "tools", "bin", "libvisualslam_amd_stamps.so")
+os.environ["VISUALSLAM_AMD_LIB"] = os.environ.get("VSA_STAMPS_LIB") or os.path.join(ROOT, "tools", "bin", "libvisualslam_amd_stamps.so")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -32,14 +32,17 @@ for _ in range(3):
 torch.cuda.synchronize()
 L = nvxcu.lib()
 n = 4096
-buf = np.zeros(4 * n, dtype=np.uint64)
+buf = np.zeros(8 * n, dtype=np.uint64)
 rc = L.visualslam_amd_debug_lk_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
 assert rc == 0, rc
-s = buf.reshape(n, 4)
+s = buf.reshape(n, 8)
 t0, t1 = s[:, 0].astype(np.int64), s[:, 1].astype(np.int64)
 hw, xcc = (s[:, 2] & 0xffffffff).astype(np.int64), (s[:, 2] >> 32).astype(np.int64) & 0xf
 wall, iters = (s[:, 3] >> 32).astype(np.int64), (s[:, 3] & 0xffffffff).astype(np.int64)
 life = t1 - t0
+ph = s[:, 4:8].astype(np.int64)
+print("phase cycles per wave (mean): level head + P commit %.0f, template pass %.0f, solve + J commit %.0f, iterations %.0f (%.0f per iteration); outside %.0f"
+      % (*ph.mean(axis=0), ph[:, 3].sum() / max(1, s[:, 3].astype(np.int64).__and__(0xffffffff).sum()), (t1 - t0 - ph.sum(axis=1)).mean()))
 print("waves", n, "iters/wave mean %.2f min %d max %d" % (iters.mean(), iters.min(), iters.max()))
 print("lifetime cycles: mean %.0f  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % (life.mean(), *np.percentile(life, [10, 50, 90]), life.max()))
 print("wall ticks (100 MHz) per wave: mean %.1f  max %d  -> shader clock ~ %.0f MHz" % (wall.mean(), wall.max(), life.mean() / wall.mean() * 100))

@@ -18,8 +18,9 @@
 //     take per-byte clamped loads into the same registers (replicate border);
 //   * latency hiding inside the wave: the search tile's loads are in flight while the template is
 //     resampled, and the next level's template loads are in flight while this level iterates;
-//   * the template is resampled at the feature's sub-pixel offset and differentiated (Scharr/32,
-//     separable, constants folded) in one streaming pass; I, Ix, Iy stay in REGISTERS for all iterations;
+//   * the template is resampled at the feature's sub-pixel offset once per value (a lane resamples its own
+//     window row and exchanges rows with its neighbours through LDS), then differentiated (Scharr/32,
+//     separable, constants folded); I, Ix, Iy stay in REGISTERS for all iterations;
 //   * pair math is scalar f32 (the packed-f32 VALU forms issue slower than two plain ones on gfx950);
 //   * sums are combined in the butterfly order the oracle mirrors, two or three sums per butterfly (lanes of
 //     different lane % 4 carry different sums; DPP quad permutes and row rotations, then the gfx950 row swaps
@@ -59,7 +60,7 @@ struct KeypointF {
 };
 
 #ifdef VSA_LK_STAMPS   // development instrumentation: per-wave start/end cycle stamps and placement
-__device__ uint64_t g_lk_stamps[4 * 8192];
+__device__ uint64_t g_lk_stamps[8 * 8192];
 #endif
 
 template <int CTRL, int ROW_MASK>
@@ -200,6 +201,8 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     constexpr int PS = 4 * PS4, JS = 4 * JS4;                                              // ... in floats
     constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
     constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * PS, JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * JS;   // tile regions
+    constexpr int TS = (WMAX + NSEG + 2) | 1;                                              // row stride of the resampled template tile
+    constexpr int TBASE = (PFLOATS > JFLOATS ? PFLOATS : JFLOATS) + 64;                    // it follows both regions and their slack
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -208,6 +211,11 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     const uint64_t st_t0 = __builtin_readcyclecounter();
     const uint64_t st_w0 = wall_clock64();
     uint32_t st_iters = 0;
+    uint64_t st_ph[4] = {0, 0, 0, 0};   // cycles in: level head + P commit, template pass, solve + J commit, iterations
+#define LK_PHASE(i) do { const uint64_t now_ = __builtin_readcyclecounter(); st_ph[i] += now_ - st_mark; st_mark = now_; } while (0)
+    uint64_t st_mark = st_t0;
+#else
+#define LK_PHASE(i) do { } while (0)
 #endif
     const uint32_t n = min(*a.prev_count, a.capacity);
     if (blockIdx.x == 0 && lane == 0) {
@@ -239,6 +247,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     const int PW = win + 3, JW = win + 1 + 2 * LK_MARGIN;
     float *P = smem;                          // template tile; dead once I/Ix/Iy are in registers
     float *J = smem;                          // search tile (aliases P)
+    float *T = smem + TBASE;                  // resampled template rows (own region: written while P is being read)
 
     // lane -> (window row, segment).  Idle lanes shadow lane 0 with cnt = 0: every lane runs the same
     // branch-free code on valid LDS data and contributes exact zeros.
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     int x0 = (lane - row * a.segs) * a.seglen;
     int cnt = min(a.seglen, win - x0);
     if (lane >= a.lanes || cnt < 0) { row = 0; x0 = 0; cnt = 0; }
-    const int lbaseP = row * PS + x0, lbaseJ = row * JS + x0;
+    const int lbaseP = row * PS + x0, lbaseJ = row * JS + x0, lbaseT = row * TS + x0;
 
     // LDS only ever holds converted pixels or these zeros (the slack a lane may over-read past its
     // segment at the end of either tile region), so idle pixels multiply finite values by exact zeros
@@ -296,44 +305,66 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         __syncthreads();   // previous level's search tile is dead
         tile_commit(tp, sp, P);
         __syncthreads();
+        LK_PHASE(0);
 
-        // template pass, streaming over the lane's P columns c = 0 .. NSEG+2 (four rows each):
-        //   v0..v2      vertical lerps of column c            -> resampled rows wy-1, wy, wy+1
-        //   t0..t2      horizontal lerps, resampled column tc = c-1
-        //   sm, df      Scharr column terms of tc (3/32 and 10/32 folded in)
-        //   pixel k = tc-2: Ix = sm[tc] - sm[tc-2], Iy from df[tc-2..tc], I = centre row at tc-1
+        // Template pass.  T(R, C), R, C = 0 .. win+1, is the template resampled at the feature's sub-pixel offset on the window
+        // plus a one-pixel ring: v(R, c) = lerp_y(P(R, c), P(R+1, c)), T(R, C) = lerp_x(v(R, C), v(R, C+1)).  A lane needs three
+        // rows of it (R = row, row+1, row+2) at columns x0 .. x0+NSEG+1, but every T value is needed by up to six lanes, so
+        //   phase 1: a lane resamples only its centre row R = row+1 (kept in registers, and stored to the T tile in LDS);
+        //            lanes 0 .. 2(win+2)-1 add one value each of the two rows no lane has as its centre (R = 0, win+1);
+        //   phase 2: it reads the rows above and below from the T tile and differentiates (Scharr/32, separable, 3/32 and 10/32
+        //            folded in): sm, df = column terms; pixel k: Ix = sm[k+2] - sm[k], Iy from df[k..k+2], I = T(row+1, k+1).
+        // Neighbouring segments store the columns they share with identical bits; columns past the window hold finite values
+        // nobody uses (pixels k >= cnt are zeroed below).
         float sxx = 0.0f, sxy = 0.0f, syy = 0.0f;
         {
-            const float *q = P + lbaseP + (p_x0 & 3);   // P(row + rr, x0 + c) = q[rr*PS + c]
-            float v0p = 0.0f, v1p = 0.0f, v2p = 0.0f;
-            float sm_p = 0.0f, sm_pp = 0.0f, df_p = 0.0f, df_pp = 0.0f, t1_p = 0.0f;
+            const float *q = P + lbaseP + (p_x0 & 3) + PS;   // P(row + 1 + rr, x0 + c) = q[rr*PS + c]
+            float tc[NSEG + 2];
+            {
+                float vp = fmaf(ay, q[PS] - q[0], q[0]);
 #pragma unroll
-            for (int c = 0; c < NSEG + 3; ++c) {
-                const float p0 = q[c], p1 = q[PS + c], p2 = q[2 * PS + c], p3 = q[3 * PS + c];
-                const float v0 = fmaf(ay, p1 - p0, p0), v1 = fmaf(ay, p2 - p1, p1), v2 = fmaf(ay, p3 - p2, p2);
-                if (c >= 1) {
-                    const float t0 = fmaf(ax, v0 - v0p, v0p), t1 = fmaf(ax, v1 - v1p, v1p), t2 = fmaf(ax, v2 - v2p, v2p);
-                    const float sm = fmaf(0.3125f, t1, 0.09375f * (t0 + t2));
-                    const float df = t2 - t0;
-                    if (c >= 3) {
-                        const int k = c - 3;
-                        float ix = sm - sm_pp;
-                        float iy = fmaf(0.3125f, df_p, 0.09375f * (df_pp + df));
-                        if (k >= cnt) { ix = 0.0f; iy = 0.0f; }   // selects, not a branch
-                        Iw[k] = t1_p;
-                        Ix[k] = ix;
-                        Iy[k] = iy;
-                        sxx = fmaf(ix, ix, sxx);
-                        sxy = fmaf(ix, iy, sxy);
-                        syy = fmaf(iy, iy, syy);
-                    }
-                    sm_pp = sm_p; sm_p = sm; df_pp = df_p; df_p = df; t1_p = t1;
+                for (int c = 1; c < NSEG + 3; ++c) {
+                    const float v = fmaf(ay, q[PS + c] - q[c], q[c]);
+                    tc[c - 1] = fmaf(ax, v - vp, vp);
+                    vp = v;
                 }
-                v0p = v0; v1p = v1; v2p = v2;
+            }
+            float *tw = T + lbaseT + TS;                       // T(row + 1, x0 + j)
+#pragma unroll
+            for (int j = 0; j < NSEG + 2; ++j) tw[j] = tc[j];
+            for (int e = lane; e < 2 * (win + 2); e += 64) {   // rows R = 0 and R = win+1
+                const int far = e >= win + 2;
+                const int C = e - (far ? win + 2 : 0), R = far ? win + 1 : 0;
+                const float *pe = P + (p_x0 & 3) + R * PS + C;
+                const float va = fmaf(ay, pe[PS] - pe[0], pe[0]), vb = fmaf(ay, pe[PS + 1] - pe[1], pe[1]);
+                T[R * TS + C] = fmaf(ax, vb - va, va);
+            }
+            __syncthreads();
+            const float *tu = T + lbaseT, *td = T + lbaseT + 2 * TS;   // T(row, x0 + j), T(row + 2, x0 + j)
+            float sm_p = 0.0f, sm_pp = 0.0f, df_p = 0.0f, df_pp = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NSEG + 2; ++j) {
+                const float up = tu[j], dn = td[j];
+                const float sm = fmaf(0.3125f, tc[j], 0.09375f * (up + dn));
+                const float df = dn - up;
+                if (j >= 2) {
+                    const int k = j - 2;
+                    float ix = sm - sm_pp;
+                    float iy = fmaf(0.3125f, df_p, 0.09375f * (df_pp + df));
+                    if (k >= cnt) { ix = 0.0f; iy = 0.0f; }   // selects, not a branch
+                    Iw[k] = tc[k + 1];
+                    Ix[k] = ix;
+                    Iy[k] = iy;
+                    sxx = fmaf(ix, ix, sxx);
+                    sxy = fmaf(ix, iy, sxy);
+                    syy = fmaf(iy, iy, syy);
+                }
+                sm_pp = sm_p; sm_p = sm; df_pp = df_p; df_p = df;
             }
         }
         float Gxx, Gxy, Gyy;
         wave_sum3(sxx, sxy, syy, lane_bit0, lane_bit1, Gxx, Gxy, Gyy);
+        LK_PHASE(1);
 
         // next level's template loads fly while this level iterates
         if (L > 0) {
@@ -360,6 +391,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         __syncthreads();   // every lane is done with P
         tile_commit(tj, sj, J);
         __syncthreads();
+        LK_PHASE(2);
 
         for (uint32_t it = 0; it < a.max_it; ++it) {
             const float cx = (ux + gx) + vx, cy = (uy + gy) + vy;
@@ -399,6 +431,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             vx += etx; vy += ety;
             if (a.use_eps && fmaf(etx, etx, ety * ety) < a.eps2) break;
         }
+        LK_PHASE(3);
         if (L > 0) { gx = 2.0f * (gx + vx); gy = 2.0f * (gy + vy); }
         else if (a.calc_error && ok) {
             // calcError: mean |I - J| over the window at the final position of level 0 (the position an iteration
@@ -450,9 +483,10 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 #ifdef VSA_LK_STAMPS
     if (lane == 0 && blockIdx.x < 8192) {
         const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        uint64_t *o = g_lk_stamps + 4 * blockIdx.x;
+        uint64_t *o = g_lk_stamps + 8 * blockIdx.x;
         o[0] = st_t0; o[1] = __builtin_readcyclecounter(); o[2] = ((uint64_t)xcc << 32) | hw;
         o[3] = ((wall_clock64() - st_w0) << 32) | st_iters;
+        o[4] = st_ph[0]; o[5] = st_ph[1]; o[6] = st_ph[2]; o[7] = st_ph[3];
     }
 #endif
 }
@@ -463,7 +497,8 @@ hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipSt
     constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;
     constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
     constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * 4 * (NDP | 1), JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * 4 * (NDJ | 1);
-    constexpr size_t lds = ((PFLOATS > JFLOATS ? PFLOATS : JFLOATS) + 64) * sizeof(float);   // tile region + zeroed slack
+    constexpr int TS = (WMAX + NSEG + 2) | 1;
+    constexpr size_t lds = ((PFLOATS > JFLOATS ? PFLOATS : JFLOATS) + 64 + (WMAX + 3) * TS) * sizeof(float);   // tile region + zeroed slack + T tile
     const dim3 grid(capacity), block(64);
     if (aligned) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false>), grid, block, lds, stream, a);
