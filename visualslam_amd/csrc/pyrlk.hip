@@ -202,7 +202,10 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
     constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * PS, JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * JS;   // tile regions
     constexpr int TS = (WMAX + NSEG + 2) | 1;                                              // row stride of the resampled template tile
-    constexpr int TBASE = (PFLOATS > JFLOATS ? PFLOATS : JFLOATS) + 64;                    // it follows both regions and their slack
+    constexpr int TBASE = PFLOATS + 64;                                                    // it follows the template tile and its slack; the
+                                                                                           // search tile, committed after the pass, may overlap it
+    constexpr int TEND = TBASE + (WMAX + 3) * TS;
+    constexpr int LDS_FLOATS = (JFLOATS + 64 > TEND) ? JFLOATS + 64 : TEND;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     const int PW = win + 3, JW = win + 1 + 2 * LK_MARGIN;
     float *P = smem;                          // template tile; dead once I/Ix/Iy are in registers
     float *J = smem;                          // search tile (aliases P)
-    float *T = smem + TBASE;                  // resampled template rows (own region: written while P is being read)
+    float *T = smem + TBASE;                  // resampled template rows (written while P is being read; dead before J is committed)
 
     // lane -> (window row, segment).  Idle lanes shadow lane 0 with cnt = 0: every lane runs the same
     // branch-free code on valid LDS data and contributes exact zeros.
@@ -257,10 +260,10 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     if (lane >= a.lanes || cnt < 0) { row = 0; x0 = 0; cnt = 0; }
     const int lbaseP = row * PS + x0, lbaseJ = row * JS + x0, lbaseT = row * TS + x0;
 
-    // LDS only ever holds converted pixels or these zeros (the slack a lane may over-read past its
-    // segment at the end of either tile region), so idle pixels multiply finite values by exact zeros
-    smem[PFLOATS + lane] = 0.0f;
-    smem[JFLOATS + lane] = 0.0f;
+    // LDS only ever holds converted pixels, resampled template values or the zeros written here (the slack a lane may
+    // over-read past its segment at the end of either tile region, T entries nobody computes), so idle pixels
+    // multiply finite values by exact zeros
+    for (int i = PFLOATS + lane; i < LDS_FLOATS; i += 64) smem[i] = 0.0f;
 
     TileSlots<NLP> sp;
     TileSlots<NLJ> sj;
@@ -498,7 +501,8 @@ hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipSt
     constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
     constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * 4 * (NDP | 1), JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * 4 * (NDJ | 1);
     constexpr int TS = (WMAX + NSEG + 2) | 1;
-    constexpr size_t lds = ((PFLOATS > JFLOATS ? PFLOATS : JFLOATS) + 64 + (WMAX + 3) * TS) * sizeof(float);   // tile region + zeroed slack + T tile
+    constexpr int TEND = PFLOATS + 64 + (WMAX + 3) * TS;   // template tile + zeroed slack + T tile; the search tile overlaps T
+    constexpr size_t lds = ((JFLOATS + 64 > TEND) ? JFLOATS + 64 : TEND) * sizeof(float);
     const dim3 grid(capacity), block(64);
     if (aligned) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true>), grid, block, lds, stream, a);
     else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false>), grid, block, lds, stream, a);
