@@ -60,7 +60,11 @@ __global__ __launch_bounds__(256) void k_rgbx_to_u8_scalar(const uint8_t *__rest
 // coordinate, so every step is the oracle's clamp-at-each-level arithmetic.
 // For 1080p / 5 levels this is ONE launch of 510 workgroups instead of four dependent launches,
 // and level 0 is read from HBM once.
-constexpr int PYR_THREADS = 1024;   // 16 waves per workgroup: short per-thread loops, latency hidden by waves
+// 8 waves per workgroup.  16 waves are a little faster when the kernel has the GPU to itself (9.3 against ~10 us at 1080p) but a
+// 16-wave, 27 KB workgroup finds a compute unit with room less often while other camera streams' PyrLK waves hold wave slots and
+// LDS: with 16 streams the whole bench runs 4 % faster with 8 waves (tools/exp_lib_ab.sh: 1024 threads 26.0 k, 512 27.1 k, 256
+// 25.9 k frames/s)
+constexpr int PYR_THREADS = 512;
 constexpr int pyr_region(int t, int up) { return up == 0 ? t : 2 * pyr_region(t, up - 1) + 3; }
 
 struct PyrFusedArgs {
