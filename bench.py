@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--streams", type=int, default=16, help="camera streams per GPU")
+    ap.add_argument("--streams", type=int, default=32, help="camera streams per GPU")
     ap.add_argument("--ring", type=int, default=8, help="pre-generated frames resident in HBM")
     ap.add_argument("--api", choices=["ovx", "thin"], default="ovx",
                     help="ovx: OpenVX graph API (default, the north-star path); thin: nvxcu primitives")
