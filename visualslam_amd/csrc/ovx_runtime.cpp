@@ -288,7 +288,7 @@ vx_status ensure_array(_vx_array *a)
     const size_t payload = (a->capacity * a->item_size + 15) & ~(size_t)15;
     void *p = nullptr;
     if (hipMalloc(&p, payload + 16) != hipSuccess) return VX_ERROR_NO_MEMORY;
-    if (hipMemset(p, 0, payload + 16) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return VX_FAILURE;
+    if (hipMemset(p, 0, payload + 16) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(p); return VX_FAILURE; }
     a->dev = static_cast<uint8_t *>(p);
     a->dev_count = reinterpret_cast<uint32_t *>(a->dev + payload);
     if (a->num_items) {
@@ -1382,7 +1382,11 @@ vx_status vxQueryContext(vx_context context, vx_enum attribute, void *ptr, vx_si
     switch (attribute) {
     case VX_CONTEXT_VENDOR_ID: { vx_uint16 v = VX_ID_DEFAULT; return query_out(ptr, size, &v, sizeof(v)); }
     case VX_CONTEXT_VERSION: { vx_uint16 v = (vx_uint16)VX_VERSION; return query_out(ptr, size, &v, sizeof(v)); }
-    case VX_CONTEXT_REFERENCES: { vx_uint32 v = (vx_uint32)context->live.size(); return query_out(ptr, size, &v, sizeof(v)); }
+    case VX_CONTEXT_REFERENCES: {
+        std::lock_guard<std::recursive_mutex> lk(context->mu);
+        vx_uint32 v = (vx_uint32)context->live.size();
+        return query_out(ptr, size, &v, sizeof(v));
+    }
     default: return VX_ERROR_NOT_SUPPORTED;
     }
 }
