@@ -194,6 +194,7 @@ __device__ __forceinline__ void harris_emit(const CornerArgs &a, const HarrisTil
 __global__ __launch_bounds__(64) void k_harris_cells(CornerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    VSA_SHORT_KERNEL_PRIORITY();
     // carve: pixel tile (HS_R rows x 64 columns) | keys
     uint8_t *tile = smem;
     uint64_t *keys = reinterpret_cast<uint64_t *>(smem + HS_R * 64);
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_compact(MergeArgs a)
 {
     __shared__ uint64_t wave_tot[MG_WAVES];
     extern __shared__ uint32_t occ_words[];  // one byte per cell: holds a surviving tracked point
+    VSA_SHORT_KERNEL_PRIORITY();
     uint8_t *occ = reinterpret_cast<uint8_t *>(occ_words);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     MG_STAMP(0);

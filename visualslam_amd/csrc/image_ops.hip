@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void k_rgbx_to_u8_vec(const uint8_t *__restric
                                                         uint8_t *__restrict__ dst, uint32_t dp,
                                                         uint32_t w, uint32_t h)
 {
+    VSA_SHORT_KERNEL_PRIORITY();
     const uint32_t x = (blockIdx.x * 64u + threadIdx.x) * 4u;
     const uint32_t y = blockIdx.y * 4u + threadIdx.y;
     if (y >= h || x >= w) return;
@@ -124,6 +125,7 @@ __device__ __forceinline__ void pyr_step(const uint8_t *src, int soff, int sox, 
 template <int NS, int T>
 __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_fused(PyrFusedArgs a)
 {
+    VSA_SHORT_KERNEL_PRIORITY();
     constexpr int R0 = pyr_region(T, NS);
     constexpr int R1 = pyr_region(T, NS - 1);
     constexpr int R2 = NS >= 2 ? pyr_region(T, NS - 2) : 1;

@@ -9,6 +9,11 @@
 
 #include <hip/hip_runtime_api.h>
 
+// Kernels of one camera stream run one after the other, and streams that share a hardware queue wait for each other, so a
+// short, latency-bound kernel (colour convert, pyramid, detector, merge) that is slowed by another stream's PyrLK waves holds
+// up its whole queue.  Their waves therefore ask for issue priority over PyrLK's (s_setprio: 0 = default ... 3 = highest).
+#define VSA_SHORT_KERNEL_PRIORITY() __builtin_amdgcn_s_setprio(3)
+
 namespace vsa {
 
 constexpr int kMaxPyrLevels = 10;
