@@ -407,10 +407,16 @@ __device__ uint64_t g_mg_stamps[16];
 #define MG_STAMP(i) do { } while (0)
 #endif
 
-constexpr uint32_t MG_THREADS = 1024, MG_WAVES = MG_THREADS / 64;
-// rounds of 64 items per wave whose data stays in registers: 8 + 8 (8192 points, 8192 cells: 1080p / cell 18 has 6420
-// cells); larger arrays (4K / cell 18 has 25680 cells) walk in blocks of 12 rounds of points and 26 of cells
-constexpr uint32_t MG_K1 = 8, MG_KT2 = 12, MG_KC2 = 26;
+// The merge is one workgroup, and what it costs a camera stream is mostly the wait for a compute unit with room for it: while
+// other streams' PyrLK waves fill the GPU (4 waves x 104 VGPRs on every SIMD) a 16-wave workgroup of 96-VGPR waves waits for a
+// whole CU to drain -- 19 us per launch under the bench's load against 8 us alone, with its queue (and the streams behind it
+// in that hardware queue) held up meanwhile.  Eight waves of at most 48 VGPRs fit beside a full set of PyrLK waves (2 x 48 =
+// the 96 VGPRs they leave per SIMD): bench 28.4 k -> 30.8 k frames/s, single stream 12.2 k -> 12.0 k.  To stay at 48 VGPRs a wave
+// walks its range in small blocks and re-reads it for the write-out (L2 hits) instead of keeping it in registers
+// (the KEEP form below: 96 VGPRs for 8 + 8 rounds; 512 threads with 8 + 13 rounds in flight and 89 VGPRs: 29.0 k).
+constexpr uint32_t MG_THREADS = 512, MG_WAVES = MG_THREADS / 64;
+// rounds of 64 items per wave and block: tracked points / cells (1080p, cell 18: a wave owns 8 rounds of points, 13 of cells)
+constexpr uint32_t MG_KT = 4, MG_KC = 7;
 
 // Every fetch below is unconditional, from an index clamped into the array, and the validity test follows once the
 // whole block of loads is out: a load inside a branch (or a select fed by one) makes the compiler wait for it where
@@ -719,10 +725,8 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
     m.flag_words = ncells <= 60u * 1024u ? (ncells + 3u) / 4u : 0u;   // beyond 60 K cells the keys are marked in place
     const size_t lds = (size_t)(m.flag_words ? m.flag_words : 1u) * 4u;
     m.cs_magic = cs > 1u ? (uint32_t)((0x100000000ull + cs - 1u) / cs) : 0u;
-    if (cap_t <= MG_K1 * MG_THREADS && ncells <= MG_K1 * MG_THREADS)
-        hipLaunchKernelGGL((k_merge_compact<true, MG_K1, MG_K1>), dim3(1), dim3(MG_THREADS), lds, stream, m);
-    else
-        hipLaunchKernelGGL((k_merge_compact<false, MG_KT2, MG_KC2>), dim3(1), dim3(MG_THREADS), lds, stream, m);
+    (void)cap_t;
+    hipLaunchKernelGGL((k_merge_compact<false, MG_KT, MG_KC>), dim3(1), dim3(MG_THREADS), lds, stream, m);
     return hipGetLastError();
 }
 
