@@ -233,6 +233,46 @@ def test_set_parameter_by_index_rebinding(ctx):
     assert ovx.query("vxQueryReference", mask, ovx.VX_REFERENCE_COUNT, C.c_uint32) == 2
 
 
+def test_rebinding_an_image_produced_inside_the_graph_unverifies(ctx):
+    """keeping the graph verified across vxSetParameterByIndex is only sound for images nobody in the graph writes
+    (the camera frame, the mask); an image another node produces -- or an ROI view of one -- changes the order"""
+    a, b, c, d = (L.vxCreateImage(ctx, 32, 32, ovx.VX_DF_IMAGE_U8) for _ in range(4))
+    g = L.vxCreateGraph(ctx)
+    n1 = L.nvxCopyImageNode(g, a, b)          # creation order: consumer first, so a stale order would be wrong
+    n0 = L.nvxCopyImageNode(g, c, d)
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    ext = L.vxCreateImage(ctx, 32, 32, ovx.VX_DF_IMAGE_U8)
+    assert L.vxSetParameterByIndex(n1, 0, ext) == ovx.VX_SUCCESS and L.vxIsGraphVerified(g) == 1     # external -> external
+    assert L.vxSetParameterByIndex(n1, 0, d) == ovx.VX_SUCCESS and L.vxIsGraphVerified(g) == 0       # now reads n0's output
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    assert L.vxSetParameterByIndex(n1, 0, ext) == ovx.VX_SUCCESS and L.vxIsGraphVerified(g) == 0     # dependency removed
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    rect = ovx.vx_rectangle_t(0, 0, 32, 32)
+    view = L.vxCreateImageFromROI(d, C.byref(rect))
+    assert L.vxGetStatus(view) == ovx.VX_SUCCESS
+    assert L.vxSetParameterByIndex(n1, 0, view) == ovx.VX_SUCCESS and L.vxIsGraphVerified(g) == 0    # a view of n0's output
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    assert L.vxSetParameterByIndex(n0, 1, ext) == ovx.VX_SUCCESS and L.vxIsGraphVerified(g) == 0     # an output rebound
+
+
+def test_pyrlk_node_reads_termination_and_window_from_its_scalars(ctx):
+    """indices 5 (termination) and 9 (window_dimension) of vxOpticalFlowPyrLKNode are scalar parameters: rebinding
+    them takes effect (verification re-checks the window range), as for every other scalar of the node"""
+    ft = _ft_graph(ctx)
+    g, lk = ft["g"], ft["nodes"]["lk"]
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    p = L.vxGetParameterByIndex(lk, 9)
+    ref = C.c_void_p()
+    assert L.vxQueryParameter(p, ovx.VX_PARAMETER_REF, C.byref(ref), C.sizeof(ref)) == ovx.VX_SUCCESS
+    assert ovx.query("vxQueryScalar", ref.value, ovx.VX_SCALAR_TYPE, C.c_int32) == ovx.VX_TYPE_SIZE
+    big = ovx.scalar(ctx, ovx.VX_TYPE_SIZE, 64)
+    assert L.vxSetParameterByIndex(lk, 9, big) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_VALUE            # 3..32 (main_feature_tracker.cpp:103-106)
+    ok = ovx.scalar(ctx, ovx.VX_TYPE_SIZE, 21)
+    assert L.vxSetParameterByIndex(lk, 9, ok) == ovx.VX_SUCCESS
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+
+
 def test_verify_rejects_bad_graphs(ctx):
     g = L.vxCreateGraph(ctx)
     assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_GRAPH                     # empty

@@ -71,6 +71,8 @@ struct _vx_context : _vx_reference {
     uint32_t *pinned = nullptr;       // 16 dwords of pinned host memory for count read-backs
     void *scratch = nullptr;          // immediate-mode detector scratch
     size_t scratch_size = 0;
+    std::mutex imm_mu;                // immediate-mode calls share `stream`, `pinned` and `scratch`: one at a time, from
+                                      // the first launch to the last read-back (camera streams may run init() on their own threads)
     std::map<std::string, _vx_kernel *> kernels;   // finalized user kernels by name (the registry holds a reference)
     vx_enum next_kernel_id = VX_KERNEL_BASE(VX_ID_DEFAULT, 0) + 0x100;
 };
@@ -161,8 +163,6 @@ struct _vx_node : _vx_reference {
     KernelKind kind = K_COLOR_CONVERT;
     std::vector<_vx_reference *> params;
     std::vector<ParamSpec> spec;
-    vx_enum termination = VX_TERM_CRITERIA_BOTH;
-    vx_size window = 0;
     vx_perf_t perf{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -720,6 +720,11 @@ vx_status sync_host_view(_vx_graph *g);
 template <typename T>
 T *param(_vx_node *n, size_t i, vx_enum type) { return i < n->params.size() ? as<T>(n->params[i], type) : nullptr; }
 
+// vxOpticalFlowPyrLKNode publishes termination (index 5, VX_TYPE_ENUM) and window_dimension (index 9, VX_TYPE_SIZE) as scalar
+// parameters: they are read where they are used, so a vxSetParameterByIndex on them takes effect like on any other scalar
+vx_enum pyrlk_termination(_vx_node *n) { auto *s = param<_vx_scalar>(n, 5, VX_TYPE_SCALAR); return s ? s->v.e : 0; }
+vx_size pyrlk_window(_vx_node *n) { auto *s = param<_vx_scalar>(n, 9, VX_TYPE_SCALAR); return s ? s->v.sz : 0; }
+
 float scalar_f32(_vx_node *n, size_t i) { auto *s = param<_vx_scalar>(n, i, VX_TYPE_SCALAR); return s ? s->v.f32 : 0.0f; }
 uint32_t scalar_u32(_vx_node *n, size_t i) { auto *s = param<_vx_scalar>(n, i, VX_TYPE_SCALAR); return s ? s->v.u32 : 0u; }
 
@@ -743,7 +748,7 @@ vx_status node_scratch(_vx_node *n)
     return VX_SUCCESS;
 }
 
-vx_status homography_node_scratch(_vx_node *n)
+vx_status homography_node_scratch(_vx_node *n, hipStream_t stream)
 {
     const size_t need = homography_scratch_bytes(homography_hypotheses(scalar_f32(n, 7), scalar_f32(n, 8), scalar_u32(n, 5)));
     if (need > n->scratch_size) {
@@ -753,8 +758,9 @@ vx_status homography_node_scratch(_vx_node *n)
         n->scratch_size = 0;
         if (hipMalloc(&n->scratch, need) != hipSuccess) return VX_ERROR_NO_MEMORY;
         n->scratch_size = need;
-        // the ticket word; this buffer is the node's alone and the kernel leaves the word zero
-        if (hipMemset(n->scratch, 0, 16) != hipSuccess) return VX_FAILURE;
+        // the ticket word, cleared on the stream the kernel runs on (a null-stream memset is not ordered against the
+        // graph's non-blocking stream); this buffer is the node's alone and the kernel leaves the word zero
+        if (hipMemsetAsync(n->scratch, 0, 16, stream) != hipSuccess) return VX_FAILURE;
     }
     return VX_SUCCESS;
 }
@@ -763,7 +769,7 @@ vx_status run_node(_vx_node *n, hipStream_t stream)
 {
     switch (n->kind) {
     case K_FIND_HOMOGRAPHY: {
-        vx_status s = homography_node_scratch(n);
+        vx_status s = homography_node_scratch(n, stream);
         if (s != VX_SUCCESS) return s;
         auto *m = param<_vx_scalar>(n, 3, VX_TYPE_SCALAR);
         return do_find_homography(param<_vx_array>(n, 0, VX_TYPE_ARRAY), param<_vx_array>(n, 1, VX_TYPE_ARRAY),
@@ -797,8 +803,8 @@ vx_status run_node(_vx_node *n, hipStream_t stream)
     case K_PYRLK:
         return do_pyrlk(param<_vx_pyramid>(n, 0, VX_TYPE_PYRAMID), param<_vx_pyramid>(n, 1, VX_TYPE_PYRAMID),
                         param<_vx_array>(n, 2, VX_TYPE_ARRAY), param<_vx_array>(n, 3, VX_TYPE_ARRAY),
-                        param<_vx_array>(n, 4, VX_TYPE_ARRAY), n->termination, param<_vx_scalar>(n, 6, VX_TYPE_SCALAR),
-                        param<_vx_scalar>(n, 7, VX_TYPE_SCALAR), param<_vx_scalar>(n, 8, VX_TYPE_SCALAR), n->window, stream);
+                        param<_vx_array>(n, 4, VX_TYPE_ARRAY), pyrlk_termination(n), param<_vx_scalar>(n, 6, VX_TYPE_SCALAR),
+                        param<_vx_scalar>(n, 7, VX_TYPE_SCALAR), param<_vx_scalar>(n, 8, VX_TYPE_SCALAR), pyrlk_window(n), stream);
     case K_HARRIS_TRACK:
     case K_FAST_TRACK: {
         vx_status s = node_scratch(n);
@@ -1032,7 +1038,7 @@ vx_status verify_graph(_vx_graph *g)
                 log_msg(ctx, nd, VX_ERROR_NOT_SUPPORTED, "vxOpticalFlowPyrLKNode: point arrays must both be NVX_TYPE_POINT2F or NVX_TYPE_KEYPOINTF");
                 return VX_ERROR_NOT_SUPPORTED;
             }
-            if (nd->window < (vx_size)kLkMinWin || nd->window > (vx_size)kLkMaxWin) return VX_ERROR_INVALID_VALUE;
+            if (pyrlk_window(nd) < (vx_size)kLkMinWin || pyrlk_window(nd) > (vx_size)kLkMaxWin) return VX_ERROR_INVALID_VALUE;
         }
         if (nd->kind == K_HARRIS_TRACK || nd->kind == K_FAST_TRACK) {
             auto *o = param<_vx_array>(nd, 1, VX_TYPE_ARRAY);
@@ -1204,6 +1210,22 @@ vx_status finish_graph(_vx_graph *g)
     return VX_SUCCESS;
 }
 
+// does any node of the graph write `r` (or memory `r` stands for: its pyramid, its ROI parents, views of it)?
+bool written_in_graph(_vx_graph *g, _vx_reference *r)
+{
+    if (!g || !r) return false;
+    std::vector<const void *> mine, theirs;
+    keys_of(r, &mine);
+    for (_vx_node *nd : g->nodes)
+        for (size_t p = 0; p < nd->params.size(); ++p) {
+            if (!nd->params[p] || nd->spec[p].dir == VX_INPUT || nd->spec[p].type == VX_TYPE_SCALAR) continue;
+            theirs.clear();
+            keys_of(nd->params[p], &theirs);
+            if (intersects(mine, theirs)) return true;
+        }
+    return false;
+}
+
 // ---- node construction -------------------------------------------------------------------------
 vx_node make_node(vx_graph graph, KernelKind kind, std::vector<ParamSpec> spec, std::vector<_vx_reference *> params,
                   bool allow_unset = false)
@@ -1277,6 +1299,7 @@ vx_status immediate_corner(vx_context context, Detector det, vx_image input, vx_
     if (mask && !valid(mask, VX_TYPE_IMAGE)) return VX_ERROR_INVALID_REFERENCE;
     if (tracked && !valid(tracked, VX_TYPE_ARRAY)) return VX_ERROR_INVALID_REFERENCE;
     if (cell == 0) return VX_ERROR_INVALID_VALUE;
+    std::lock_guard<std::mutex> imm(context->imm_mu);
     if (hipSetDevice(context->device) != hipSuccess) return VX_FAILURE;
     const size_t need = corner_track_scratch_bytes(in->width, in->height, cell);
     vx_status s = immediate_scratch(context, need);
@@ -2072,6 +2095,11 @@ vx_status vxSetParameterByIndex(vx_node node, vx_uint32 index, vx_reference valu
     } else if (sp.optional && sp.dir == VX_INPUT && sp.type == VX_TYPE_IMAGE) {
         same_meta = true;             // an optional read-only image (the mask) appearing or disappearing changes no order
     }
+    // ... unless the old or the new image is produced inside this graph (directly, as an ROI view or through its
+    // parent): the data dependencies then change and the execution order has to be rebuilt
+    if (same_meta && sp.type == VX_TYPE_IMAGE && n->graph && n->graph->verified &&
+        (sp.dir != VX_INPUT || written_in_graph(n->graph, old) || written_in_graph(n->graph, value)))
+        same_meta = false;
     retain(value);
     n->params[index] = value;
     release_ref(old);
@@ -2336,7 +2364,6 @@ vx_node vxOpticalFlowPyrLKNode(vx_graph graph, vx_pyramid old_images, vx_pyramid
                           { R(old_images), R(new_images), R(old_points), R(new_points_estimates), R(new_points), t,
                             R(epsilon), R(num_iterations), R(use_initial_estimate), w });
     release_ref(t); release_ref(w);
-    if (valid(n, VX_TYPE_NODE)) { n->termination = termination; n->window = window_dimension; }
     return n;
 }
 
@@ -2450,6 +2477,8 @@ static vx_status immediate_begin(vx_context context)
 
 vx_status vxuColorConvert(vx_context context, vx_image input, vx_image output)
 {
+    if (!usable(context)) return VX_ERROR_INVALID_REFERENCE;
+    std::lock_guard<std::mutex> imm(context->imm_mu);
     vx_status s = immediate_begin(context);
     if (s != VX_SUCCESS) return s;
     s = do_color_convert(as<_vx_image>(input, VX_TYPE_IMAGE), as<_vx_image>(output, VX_TYPE_IMAGE), context->stream);
@@ -2460,6 +2489,8 @@ vx_status nvxuFindHomography(vx_context context, vx_array srcPoints, vx_array ds
                              vx_float32 threshold, vx_uint32 maxEstimateIters, vx_uint32 maxRefineIters, vx_float32 confidence,
                              vx_float32 outlierRatio, vx_array mask)
 {
+    if (!usable(context)) return VX_ERROR_INVALID_REFERENCE;
+    std::lock_guard<std::mutex> imm(context->imm_mu);
     vx_status s = immediate_begin(context);
     if (s != VX_SUCCESS) return s;
     auto *m = as<_vx_matrix>(homography, VX_TYPE_MATRIX);
@@ -2480,6 +2511,8 @@ vx_status nvxuFindHomography(vx_context context, vx_array srcPoints, vx_array ds
 
 vx_status vxuWarpPerspective(vx_context context, vx_image input, vx_matrix matrix, vx_enum type, vx_image output)
 {
+    if (!usable(context)) return VX_ERROR_INVALID_REFERENCE;
+    std::lock_guard<std::mutex> imm(context->imm_mu);
     vx_status s = immediate_begin(context);
     if (s != VX_SUCCESS) return s;
     vx_border_t b{};
@@ -2491,6 +2524,8 @@ vx_status vxuWarpPerspective(vx_context context, vx_image input, vx_matrix matri
 
 vx_status nvxuCopyImage(vx_context context, vx_image src, vx_image dst)
 {
+    if (!usable(context)) return VX_ERROR_INVALID_REFERENCE;
+    std::lock_guard<std::mutex> imm(context->imm_mu);
     vx_status s = immediate_begin(context);
     if (s != VX_SUCCESS) return s;
     s = do_copy_image(as<_vx_image>(src, VX_TYPE_IMAGE), as<_vx_image>(dst, VX_TYPE_IMAGE), context->stream);
@@ -2499,6 +2534,8 @@ vx_status nvxuCopyImage(vx_context context, vx_image src, vx_image dst)
 
 vx_status vxuGaussianPyramid(vx_context context, vx_image input, vx_pyramid gaussian)
 {
+    if (!usable(context)) return VX_ERROR_INVALID_REFERENCE;
+    std::lock_guard<std::mutex> imm(context->imm_mu);
     vx_status s = immediate_begin(context);
     if (s != VX_SUCCESS) return s;
     s = do_gaussian_pyramid(as<_vx_image>(input, VX_TYPE_IMAGE), as<_vx_pyramid>(gaussian, VX_TYPE_PYRAMID), context->stream);
@@ -2509,6 +2546,8 @@ vx_status vxuOpticalFlowPyrLK(vx_context context, vx_pyramid old_images, vx_pyra
                               vx_array new_points_estimates, vx_array new_points, vx_enum termination, vx_scalar epsilon,
                               vx_scalar num_iterations, vx_scalar use_initial_estimate, vx_size window_dimension)
 {
+    if (!usable(context)) return VX_ERROR_INVALID_REFERENCE;
+    std::lock_guard<std::mutex> imm(context->imm_mu);
     vx_status s = immediate_begin(context);
     if (s != VX_SUCCESS) return s;
     auto *out = as<_vx_array>(new_points, VX_TYPE_ARRAY);

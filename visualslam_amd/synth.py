@@ -72,3 +72,43 @@ def to_rgbx(gray):
 def color_rgbx(width, height, seed):
     rng = np.random.default_rng(seed)
     return rng.integers(0, 256, (height, width, 4), dtype=np.uint8)
+
+
+def _warp_affine_rgb(src, out_w, out_h, m):
+    """out(x, y) = src(m @ (x, y, 1)), bilinear, replicate border; src (h, w, 3) u8, m 2x3 float32 -> (out_h, out_w, 3) u8.
+    float32 arithmetic in a fixed order, numpy only."""
+    h, w = src.shape[:2]
+    xs, ys = np.meshgrid(np.arange(out_w, dtype=np.float32), np.arange(out_h, dtype=np.float32))
+    m = np.asarray(m, np.float32)
+    sx = m[0, 0] * xs + m[0, 1] * ys + m[0, 2]
+    sy = m[1, 0] * xs + m[1, 1] * ys + m[1, 2]
+    sx = np.clip(sx, 0, w - 1).astype(np.float32)
+    sy = np.clip(sy, 0, h - 1).astype(np.float32)
+    x0, y0 = np.floor(sx).astype(np.int32), np.floor(sy).astype(np.int32)
+    x1, y1 = np.minimum(x0 + 1, w - 1), np.minimum(y0 + 1, h - 1)
+    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+    s = src.astype(np.float32)
+    top = s[y0, x0] * (1 - fx) + s[y0, x1] * fx
+    bot = s[y1, x0] * (1 - fx) + s[y1, x1] * fx
+    return np.clip(np.rint(top * (1 - fy) + bot * fy), 0, 255).astype(np.uint8)
+
+
+def c1_sequence(sources, n_frames, width=640, height=480):
+    """BASELINE configs[0] stand-in: 640x480 RGBX frames synthesised from the still images the
+    reference ships (tests/golden/c1_sources.npz: 320x240 RGB crops of lena.jpg / baboon.jpg).  Each clip is the source
+    upsampled 2x under a view that rotates 0.15 degrees, zooms 0.3 % and pans (1.3, -0.7) px per frame; the first half
+    of the sequence shows lena, the second half baboon (a scene cut: every track is lost and detection starts over)."""
+    clips = [sources["lena_rgb"], sources["baboon_rgb"]]
+    cut = (n_frames + 1) // 2
+    frames = []
+    for t in range(n_frames):
+        src, k = (clips[0], t) if t < cut else (clips[1], t - cut)
+        a = np.deg2rad(0.15 * k)
+        z = 1.0 / (1.0 + 0.003 * k)
+        cx, cy = 0.5 * (width - 1), 0.5 * (height - 1)
+        c, s = np.cos(a) * z, np.sin(a) * z
+        # output pixel -> source pixel: rotate/zoom about the frame centre, pan, then the 2x scale of the source
+        m = np.array([[c, -s, cx - c * cx + s * cy - 1.3 * k], [s, c, cy - s * cx - c * cy + 0.7 * k]], np.float64) * 0.5
+        rgb = _warp_affine_rgb(src, width, height, m)
+        frames.append(np.concatenate([rgb, np.full((height, width, 1), 255, np.uint8)], axis=2))
+    return frames
