@@ -183,6 +183,20 @@ nvxcu_error_status_e nvxcuHarrisTrack(const nvxcu_image_t *input, const nvxcu_ar
                                       size_t *num_corners_dev_ptr, const nvxcu_tmp_buf_t *tmp_buf,
                                       const nvxcu_exec_target_t *exec_target);
 
+/* NO COUNTERPART IN THE REFERENCE.  nvxcuHarrisTrack for callers that cannot allocate or be handed a workspace:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, results and
+ * error codes as nvxcuHarrisTrack minus tmp_buf: the per-cell keys live in a device array inside the library
+ * (8 bytes x NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS = 512 KiB per GPU, held until the process ends), and the call
+ * allocates nothing.  Limits: ceil(width / cell_size) * ceil(height / cell_size) <= NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS,
+ * else NVXCU_ERROR_NO_MEMORY (1080p and 4K frames at cell 18 use 6 420 and 25 680 cells).  The device that owns
+ * exec_target's stream must be the current device.  All calls on one GPU share that GPU's array: calls that overlap
+ * on one GPU (two streams, two threads) race -- serialise them or use nvxcuHarrisTrack with separate tmp_bufs. */
+#define NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS 65536u
+nvxcu_error_status_e nvxcuHarrisTrack_NoAlloc(const nvxcu_image_t *input, const nvxcu_array_t *output,
+                                              const nvxcu_image_t *mask, const nvxcu_array_t *tracked_points,
+                                              float k, float threshold, uint32_t cell_size,
+                                              size_t *num_corners_dev_ptr, const nvxcu_exec_target_t *exec_target);
+
 /* replaces nvxcuFastTrack_GetBufSize -- feature_tracker_nvxcu.cpp:436-440 */
 nvxcu_tmp_buf_size_t nvxcuFastTrack_GetBufSize(uint32_t width, uint32_t height, nvxcu_df_image_e format,
                                                nvxcu_array_item_type_e item_type, uint32_t capacity,

@@ -1,12 +1,43 @@
 // nvxcu_api.cpp -- the thin C ABI (include/NVX/nvxcu.h): argument validation and launches.
 // Stateless: every buffer is caller-owned, every launch goes to the caller's HIP stream, nothing
 // is allocated or synchronised here (callers may capture these calls into a HIP graph).
+#include <hip/hip_runtime.h>
+
 #include <NVX/nvxcu.h>
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "kernels.hpp"
+
+// ---- the cell-key buffer of nvxcuHarrisTrack_NoAlloc -------------------------------------------------------------
+// One 64-bit key per detector cell, in a file-scope device array instead of the caller's tmp_buf.  Every GPU the
+// library runs on holds its own copy (512 KiB) at its own address until the process ends.  In host code the array's
+// name is only a handle for hipGetSymbolAddress: the address kernels and copies take is the one looked up below,
+// once per device, with that device current.
+static __device__ __align__(256) unsigned long long scratch[NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS];
+
+static constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mu;
+static void *g_scratch_ptr[kMaxDevices];      // device address of `scratch` on device i, looked up on first use
+
+// the current device's copy of `scratch`; nullptr (and *err set) when the lookup fails
+static void *static_scratch(hipError_t *err)
+{
+    int dev = -1;
+    *err = hipGetDevice(&dev);
+    if (*err != hipSuccess) return nullptr;
+    if (dev < 0 || dev >= kMaxDevices) { *err = hipErrorInvalidDevice; return nullptr; }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        *err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (*err != hipSuccess || !ptr) { if (*err == hipSuccess) *err = hipErrorInvalidSymbol; return nullptr; }
+        g_scratch_ptr[dev] = ptr;
+    }
+    return g_scratch_ptr[dev];
+}
 
 namespace {
 
@@ -73,7 +104,7 @@ nvxcu_error_status_e corner_track(Detector det, const nvxcu_image_t *input, cons
                                   const nvxcu_image_t *mask, const nvxcu_array_t *tracked,
                                   float k, float threshold, uint32_t fast_n, uint32_t cell_size,
                                   size_t *num_corners, const nvxcu_tmp_buf_t *tmp,
-                                  const nvxcu_exec_target_t *exec_target)
+                                  const nvxcu_exec_target_t *exec_target, bool static_keys = false)
 {
     hipStream_t stream;
     const auto *in = as_pl(input);
@@ -107,7 +138,18 @@ nvxcu_error_status_e corner_track(Detector det, const nvxcu_image_t *input, cons
     }
     if (det == kFast && (fast_n < 9 || fast_n > 12 || threshold >= 255.0f)) return NVXCU_ERROR_INVALID_PARAMETERS;
     const size_t need = corner_track_scratch_bytes(in->base.width, in->base.height, cell_size);
-    if (!tmp || !tmp->dev_ptr || ((uintptr_t)tmp->dev_ptr & 7u)) return need ? NVXCU_ERROR_INVALID_PARAMETERS : NVXCU_FAILURE;
+    void *keys = nullptr;
+    if (static_keys) {
+        // the keys of every cell are rewritten by each call (k_harris_cells stores all of them), so the array needs
+        // no clearing between calls although it keeps the previous call's contents
+        if (need > sizeof(unsigned long long) * NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS) return NVXCU_ERROR_NO_MEMORY;
+        hipError_t e = hipSuccess;
+        keys = static_scratch(&e);
+        if (!keys) return NVXCU_FAILURE;
+    } else {
+        if (!tmp || !tmp->dev_ptr || ((uintptr_t)tmp->dev_ptr & 7u)) return need ? NVXCU_ERROR_INVALID_PARAMETERS : NVXCU_FAILURE;
+        keys = tmp->dev_ptr;
+    }
     p.out = out->dev_ptr;
     p.out_count = out->num_items_dev_ptr;
     p.out_capacity = out->base.capacity;
@@ -116,7 +158,7 @@ nvxcu_error_status_e corner_track(Detector det, const nvxcu_image_t *input, cons
     p.threshold = threshold;
     p.fast_n = fast_n;
     p.cell_size = cell_size;
-    p.scratch = tmp->dev_ptr;
+    p.scratch = keys;
     return from_hip(launch_corner_track(p, stream));
 }
 
@@ -187,6 +229,15 @@ nvxcu_error_status_e nvxcuHarrisTrack(const nvxcu_image_t *input, const nvxcu_ar
 {
     return corner_track(kHarris, input, output, mask, tracked_points, k, threshold, 0, cell_size,
                         num_corners_dev_ptr, tmp_buf, exec_target);
+}
+
+nvxcu_error_status_e nvxcuHarrisTrack_NoAlloc(const nvxcu_image_t *input, const nvxcu_array_t *output,
+                                              const nvxcu_image_t *mask, const nvxcu_array_t *tracked_points,
+                                              float k, float threshold, uint32_t cell_size,
+                                              size_t *num_corners_dev_ptr, const nvxcu_exec_target_t *exec_target)
+{
+    return corner_track(kHarris, input, output, mask, tracked_points, k, threshold, 0, cell_size,
+                        num_corners_dev_ptr, nullptr, exec_target, /*static_keys=*/true);
 }
 
 nvxcu_tmp_buf_size_t nvxcuFastTrack_GetBufSize(uint32_t width, uint32_t height, nvxcu_df_image_e,

@@ -19,6 +19,8 @@ def _fourcc(s):
 
 NVXCU_SUCCESS = 0
 NVXCU_FAILURE = -1
+NVXCU_ERROR_NO_MEMORY = -8
+NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS = 65536
 NVXCU_ERROR_NOT_SUPPORTED = -3
 NVXCU_ERROR_INVALID_PARAMETERS = -10
 NVXCU_ERROR_INVALID_FORMAT = -14
@@ -115,6 +117,8 @@ def lib():
             fn.restype = nvxcu_tmp_buf_size_t
         L.nvxcuHarrisTrack.argtypes = [P, P, P, P, f32, f32, u32, P, P, P]
         L.nvxcuHarrisTrack.restype = C.c_int
+        L.nvxcuHarrisTrack_NoAlloc.argtypes = [P, P, P, P, f32, f32, u32, P, P]
+        L.nvxcuHarrisTrack_NoAlloc.restype = C.c_int
         L.nvxcuFastTrack.argtypes = [P, P, P, P, u32, u32, u32, P, P, P]
         L.nvxcuFastTrack.restype = C.c_int
         L.nvxcuOpticalFlowPyrLK_GetBufSize.argtypes = [u32, u32, u32, f32, C.c_int, u32, u32, u32, P, P]
@@ -205,6 +209,12 @@ def fast_track_buf_size(width, height, item_type, capacity, cell_size):
 def harris_track(image, out, mask, tracked, k, threshold, cell_size, num_corners_dev_ptr, tmp, target):
     return lib().nvxcuHarrisTrack(_ref(image), _ref(out), _ref(mask), _ref(tracked), k, threshold, cell_size,
                                   num_corners_dev_ptr, _ref(tmp), target.ptr)
+
+
+def harris_track_noalloc(image, out, mask, tracked, k, threshold, cell_size, num_corners_dev_ptr, target):
+    """nvxcuHarrisTrack_NoAlloc: the cell keys live in a device array inside the library (no tmp_buf)"""
+    return lib().nvxcuHarrisTrack_NoAlloc(_ref(image), _ref(out), _ref(mask), _ref(tracked), k, threshold, cell_size,
+                                          num_corners_dev_ptr, target.ptr)
 
 
 def fast_track(image, out, mask, tracked, fast_type, threshold, cell_size, num_corners_dev_ptr, tmp, target):
