@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec @1080p with 4k PyrLK tracks (BASELINE.json metric), N GPUs of one node.
 
-A step = one frame on each of S independent camera streams of this GPU (colour convert ->
-5-level Gaussian pyramid -> PyrLK 21x21 on <=4096 points -> Harris track/merge), inputs resident
-in HBM (a ring of pre-generated RGBX frames).  Streams are sharded one-or-more per GPU; there is
-no data-path collective -- the process group only carries the timing
-barrier and the max-over-ranks reduction.
+A step = one frame on each of S independent camera streams of this GPU (colour convert -> Gaussian pyramid ->
+PyrLK -> Harris/FAST track and merge), inputs resident in HBM (a ring of pre-generated RGBX frames).  Streams are
+sharded one-or-more per GPU; there is no data-path collective -- the process group only
+carries the timing barrier and the max-over-ranks reduction.
 
-  python bench.py [--gpus N --steps K --warmup W --streams S]
+  python bench.py [--gpus N --steps K --warmup W --streams S --config c1|c2|c3 --homography]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+--gpus N without a launcher (WORLD_SIZE unset) starts the N ranks itself, as fresh child processes, before this
+process has touched a GPU.  The default line is BASELINE configs[1] (--config c2); c1 and c3 are configs[0] and [2],
+--homography is configs[4]: other workloads, never the headline line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,20 +25,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# SURVEY.md section 8d, configs[1]: algorithmic (compulsory, unique) bytes per frame
-WIDTH, HEIGHT, LEVELS, CAPACITY, CELL, WIN, ITERS = 1920, 1080, 5, 4096, 18, 21, 5
-BYTES_PYRAMID = 2754000 + 688560
-BYTES_DETECT = 2073600 + 32768
-BYTES_LK = 5524320 + 65536          # both pyramids read once + 16 B per point: the PyrLK launch
-BYTES_CVT = 10368000
-BYTES_FRAME = BYTES_PYRAMID + BYTES_DETECT + BYTES_LK + BYTES_CVT
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec
-WORKLOAD = "1080p synthetic RGBX frames, 5-level pyramid, 4k Harris features (cell 18), 21x21 PyrLK window, 5 iters"
+
+# the workloads and their ALGORITHMIC (compulsory, unique) bytes per frame
+CONFIGS = {
+    "c1": dict(baseline_config=0, width=640, height=480, levels=6, capacity=2000, cell=18, win=6, iters=5,
+               harris=True, harris_thresh=2000.0, ring=64, streams=32,
+               frames="640x480 RGBX frames synthesised from warps of the reference's lena.jpg / baboon.jpg "
+                      "(tests/golden/c1_sources.npz; the bundled video named by configs[0] is not in the repository)",
+               workload="640x480 frames, 6-level pyramid, <=2000 Harris features (cell 18, k 0.04, threshold 2000), 6x6 PyrLK window, "
+                        "5 iters (data/feature_tracker_demo_config.ini)",
+               bytes=dict(pyramid=409200 + 102300, detect=307200 + 16000, lk=819000 + 32000, cvt=1536000),
+               lk_kernel="k_pyrlk<2,10,true>"),
+    "c2": dict(baseline_config=1, width=1920, height=1080, levels=5, capacity=4096, cell=18, win=21, iters=5,
+               harris=True, harris_thresh=100.0, ring=64, streams=32,
+               frames="1080p synthetic RGBX frames (seed 1234: low-pass noise + blobs, known sub-pixel drift, per-frame noise)",
+               workload="1080p synthetic RGBX frames, 5-level pyramid, 4k Harris features (cell 18), 21x21 PyrLK window, 5 iters",
+               bytes=dict(pyramid=2754000 + 688560, detect=2073600 + 32768, lk=5524320 + 65536, cvt=10368000),
+               lk_kernel="k_pyrlk<7,21,true>"),
+    "c3": dict(baseline_config=2, width=3840, height=2160, levels=7, capacity=10000, cell=18, win=21, iters=5,
+               harris=False, harris_thresh=100.0, ring=16, streams=16,
+               frames="4K synthetic RGBX frames (seed 1234: low-pass noise + blobs, known sub-pixel drift, per-frame noise)",
+               workload="4K synthetic RGBX frames, 7-level pyramid, FAST-9 (threshold 25) track with 10k features (cell 18), 21x21 PyrLK window, 5 iters",
+               bytes=dict(pyramid=11056560 + 2764200, detect=8294400 + 80000, lk=22117200 + 160000, cvt=41472000),
+               lk_kernel="k_pyrlk<7,21,true>"),
+}
 
 
 def shard_streams(total_streams, world_size, rank):
     """camera stream s runs on rank s % world_size (independent units, no exchange step)"""
     return [s for s in range(total_streams) if s % world_size == rank]
+
+
+def rank_device(local_rank, device_count):
+    """one GPU per rank; with fewer GPUs than ranks (a rehearsal on a 1-GPU box) ranks share GPUs round-robin"""
+    return local_rank % max(device_count, 1)
 
 
 def reduce_max(value, world_size):
@@ -46,29 +72,87 @@ def reduce_max(value, world_size):
     return float(t.item())
 
 
+def gather_floats(value, world_size):
+    if world_size == 1:
+        return [value]
+    import torch
+    import torch.distributed as dist
+    out = [torch.zeros(1, dtype=torch.float64) for _ in range(world_size)]
+    dist.all_gather(out, torch.tensor([value], dtype=torch.float64))
+    return [float(t.item()) for t in out]
+
+
 def barrier(world_size):
     if world_size > 1:
         import torch.distributed as dist
         dist.barrier()
 
 
-def cpu_baseline(frames_rgbx, params, budget_s=12.0, max_frames=48):
-    """The oracle (a port: the reference implementation is closed-source) timed on this host's
-    cores, OpenMP over points/rows, on a bounded sample of the same workload."""
+def make_frames(cfg, n):
+    """the host copies of the frame ring (also what the CPU baseline runs on)"""
+    import numpy as np
+
+    from visualslam_amd import synth
+    if cfg["baseline_config"] == 0:
+        src = np.load(os.path.join(ROOT, "tests", "golden", "c1_sources.npz"))
+        return synth.c1_sequence(src, n, cfg["width"], cfg["height"])
+    base = synth.base_frame(cfg["width"], cfg["height"], 1234)
+    return [synth.to_rgbx(synth.gray_frame(base, t, 1234)) for t in range(n)]
+
+
+def cpu_baseline(frames_rgbx, params, budget_s=10.0):
+    """The oracle (a port: the reference implementation is closed-source) timed on this host's cores on a bounded
+    sample of the same workload: the OpenMP build on all host threads, median of 200 frames
+    after 20 warm-up frames, and the scalar build on one thread, median of as many frames as fit in the budget
+    (after 2 warm-ups).  `value` is the OpenMP figure; a reported baseline, never credit."""
+    import numpy as np
+
     from oracle.pipeline import OracleTracker
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or len(os.sched_getaffinity(0))
     os.environ["OMP_NUM_THREADS"] = str(threads)
-    trk = OracleTracker(params, omp=True)
-    trk.init(frames_rgbx[0])
-    n, t0 = 0, time.perf_counter()
-    while n < max_frames:
-        trk.track(frames_rgbx[(n + 1) % len(frames_rgbx)])
-        n += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} frames of the same 1080p workload through oracle/ (OpenMP, {threads} threads)"}
+
+    def run(omp, warm, frames, budget):
+        trk = OracleTracker(params, omp=omp)
+        trk.init(frames_rgbx[0])
+        times, t_end = [], time.perf_counter() + budget
+        for k in range(warm + frames):
+            t0 = time.perf_counter()
+            trk.track(frames_rgbx[(k + 1) % len(frames_rgbx)])
+            if k >= warm:
+                times.append(time.perf_counter() - t0)
+            if time.perf_counter() > t_end and len(times) >= 5:
+                break
+        return 1.0 / float(np.median(times)), len(times)
+
+    omp_fps, omp_n = run(True, 20, 200, 3.0 * budget_s)
+    one_fps, one_n = run(False, 2, 200, budget_s)
+    return {"value": omp_fps, "unit": "frames/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": one_fps, "cores": 1, "frames": one_n},
+            "sample": f"oracle/ on the same workload and frames: OpenMP build, {threads} threads, median of {omp_n} frames after 20 warm-ups; "
+                      f"scalar build, 1 thread, median of {one_n} frames after 2 warm-ups (time-bounded)"}
+
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def launch_ranks(args, argv):
+    """--gpus N with no launcher: start the N ranks as fresh child processes (this parent never touches a GPU, and
+    nothing that has initialised a GPU is ever re-executed).  Rank 0's stdout carries the JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    children = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    codes = [c.wait() for c in children]
+    return max(abs(c) for c in codes)
 
 
 def main():
@@ -76,8 +160,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--streams", type=int, default=32, help="camera streams per GPU")
-    ap.add_argument("--ring", type=int, default=8, help="pre-generated frames resident in HBM")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="c2 = BASELINE configs[1], the headline (default); c1 = configs[0] (640x480, demo ini); c3 = configs[2] (4K, FAST, 10k features)")
+    ap.add_argument("--streams", type=int, default=0, help="camera streams per GPU (default: 32; 16 for c3)")
+    ap.add_argument("--ring", type=int, default=0, help="pre-generated frames resident in HBM (default: 64, SURVEY.md section 8d; 16 for c3)")
     ap.add_argument("--api", choices=["ovx", "thin"], default="ovx",
                     help="ovx: OpenVX graph API (default, the north-star path); thin: nvxcu primitives")
     ap.add_argument("--host-threads", type=int, default=1,
@@ -90,18 +176,37 @@ def main():
                     help="BASELINE configs[4]: append nvxFindHomographyNode (batched RANSAC on the PyrLK matches, the video "
                          "stabilizer's arguments) to every stream's graph; a separate workload, never the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print this rank's device and camera streams as one JSON line and exit (no GPU is touched)")
+    ap.add_argument("--dry-run-devices", type=int, default=0, help="--dry-run: pretend the node has this many GPUs (default: --gpus)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.streams = args.streams or cfg["streams"]
+    args.ring = args.ring or cfg["ring"]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # weak scaling: S streams on every GPU; global stream ids sharded round-robin over ranks
+    my_streams = shard_streams(args.streams * world, world, rank)
+    assert len(my_streams) == args.streams
+    phases = [(s * 3) % args.ring for s in my_streams]     # streams look at different frames
+
+    if args.dry_run:
+        dev = rank_device(local_rank, args.dry_run_devices or args.gpus)
+        print(json.dumps({"rank": rank, "world": world, "device": dev, "streams": my_streams, "phases": phases}), flush=True)
+        return
 
     import numpy as np
     import torch
 
-    from visualslam_amd import nvxcu, synth
+    from visualslam_amd import nvxcu
     from visualslam_amd.thin_tracker import Params
 
     if world > 1:
@@ -109,30 +214,25 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    # one GPU per rank; on a box with fewer GPUs than ranks (a rehearsal) ranks share GPUs round-robin
-    local_device = local_rank % torch.cuda.device_count()
+    local_device = rank_device(local_rank, torch.cuda.device_count())
     torch.cuda.set_device(local_device)
     os.environ["VISUALSLAM_AMD_DEVICE"] = str(local_device)     # vxCreateContext binds this rank's GPU explicitly
     device = f"cuda:{local_device}"
     nvxcu.lib()
 
-    params = Params(pyr_levels=LEVELS, lk_num_iters=ITERS, lk_win_size=WIN, array_capacity=CAPACITY,
-                    detector_cell_size=CELL, use_harris_detector=True, harris_k=0.04, harris_thresh=100.0)
-
-    # weak scaling: S streams on every GPU; global stream ids sharded round-robin over ranks
-    my_streams = shard_streams(args.streams * world, world, rank)
-    assert len(my_streams) == args.streams
-
-    base = synth.base_frame(WIDTH, HEIGHT, 1234)
-    host_frames = [synth.to_rgbx(synth.gray_frame(base, t, 1234)) for t in range(args.ring)]
-    phases = [(s * 3) % args.ring for s in my_streams]     # streams look at different frames
+    W, H = cfg["width"], cfg["height"]
+    params = Params(pyr_levels=cfg["levels"], lk_num_iters=cfg["iters"], lk_win_size=cfg["win"], array_capacity=cfg["capacity"],
+                    detector_cell_size=cfg["cell"], use_harris_detector=cfg["harris"], harris_k=0.04, harris_thresh=cfg["harris_thresh"],
+                    fast_type=9, fast_thresh=25)
+    host_frames = make_frames(cfg, args.ring)
 
     if args.homography and args.api != "ovx":
         raise SystemExit("--homography needs --api ovx (nvxFindHomographyNode is a graph node)")
+    driver = None
     if args.api == "ovx":
         # the north-star path: one OpenVX graph per camera stream (ColorConvert -> GaussianPyramid ->
         # OpticalFlowPyrLK -> HarrisTrack), per frame vxSetParameterByIndex x2 + vxAgeDelay x2 +
-        # vxScheduleGraph, as demos/feature_tracker/feature_tracker.cpp:216-224 drives it
+        # vxProcessGraph, as demos/feature_tracker/feature_tracker.cpp:216-224 drives it
         import ctypes as C
         from visualslam_amd import ovx
         from visualslam_amd.vx_tracker import VxFeatureTracker
@@ -141,14 +241,10 @@ def main():
         ovx.check(L.vxGetStatus(ctx), "vxCreateContext")
         ring = []
         for f in host_frames:
-            img = L.vxCreateImage(ctx, WIDTH, HEIGHT, ovx.VX_DF_IMAGE_RGBX)
+            img = L.vxCreateImage(ctx, W, H, ovx.VX_DF_IMAGE_RGBX)
             ovx.write_image(img, f)
             ring.append(img)
-        trackers = [VxFeatureTracker(ctx, params, WIDTH, HEIGHT, ring[ph], None, homography=args.homography) for ph in phases]
-        if args.homography:
-            ovx.check(L.vxDirective(trackers[0].hg, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
-        # HIP events around the PyrLK node of stream 0 only (two event records per frame on that graph's stream)
-        ovx.check(L.vxDirective(trackers[0].lk, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
+        trackers = [VxFeatureTracker(ctx, params, W, H, ring[ph], None, homography=args.homography) for ph in phases]
 
         def step(k):
             for trk, ph in zip(trackers, phases):
@@ -163,44 +259,46 @@ def main():
             for k in range(k0, k0 + n):
                 trk.track(ring[(ph + 1 + k) % args.ring], None)
 
-        native = None
         if args.host_threads and args.driver == "native":
+            # persistent native host threads, released together for each run: a timed run holds the per-frame API calls only
             drv = C.CDLL(os.path.join(os.path.dirname(nvxcu.LIB_PATH), "libvsa_stream_driver.so"))
-            n = len(trackers)
             arr = lambda xs: (C.c_void_p * len(xs))(*xs)    # noqa: E731
-            drv.vsa_drive_streams.restype = C.c_int
-            drv.vsa_drive_streams.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
-            handles = (arr([t.g for t in trackers]), arr([t.cvt for t in trackers]), arr([t.det for t in trackers]),
-                       arr([t.pyr_delay for t in trackers]), arr([t.pts_delay for t in trackers]), arr(ring))
+            drv.vsa_driver_create.restype = C.c_void_p
+            drv.vsa_driver_create.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_int)]
+            drv.vsa_driver_run.restype = C.c_int
+            drv.vsa_driver_run.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            drv.vsa_driver_destroy.argtypes = [C.c_void_p]
 
-            def native(k0, n_frames):
-                ovx.check(drv.vsa_drive_streams(n, *handles, len(ring), (C.c_int * n)(*phases), k0, n_frames), "vsa_drive_streams")
+            def make_driver(trks, phs):
+                n = len(trks)
+                h = drv.vsa_driver_create(n, arr([t.g for t in trks]), arr([t.cvt for t in trks]), arr([t.det for t in trks]),
+                                          arr([t.pyr_delay for t in trks]), arr([t.pts_delay for t in trks]), arr(ring), len(ring),
+                                          (C.c_int * n)(*phs))
+                assert h, "vsa_driver_create"
+                return h
+            driver = make_driver(trackers, phases)
 
-        def lk_launch_ms():
-            perf = ovx.query("vxQueryNode", trackers[0].lk, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
-            return perf.avg * 1e-6, int(perf.num)
+        def node_perf(node):
+            perf = ovx.query("vxQueryNode", node, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
+            return int(perf.sum), int(perf.num)
 
         def counts():
             cur = [trk.curr() for trk in trackers]
             return [int((c[:, 0] >= 0).sum()) for c in cur], [len(c) for c in cur]
         api_desc = ("OpenVX graph C API (VX/vx.h): one graph + HIP stream per camera stream, " +
-                    (("one native host thread per stream calling vxProcessGraph" if native else "one Python thread per stream calling vxProcessGraph")
+                    (("one persistent native host thread per stream calling vxProcessGraph" if driver else "one Python thread per stream calling vxProcessGraph")
                      if args.host_threads else "one host thread, vxScheduleGraph/vxWaitGraph"))
     else:
         from visualslam_amd.devmem import DeviceImage
         from visualslam_amd.thin_tracker import ThinFeatureTracker
-        ring = [DeviceImage(WIDTH, HEIGHT, nvxcu.NVXCU_DF_IMAGE_RGBX, device).upload(f) for f in host_frames]
-        trackers = [ThinFeatureTracker(params, WIDTH, HEIGHT, device, torch.cuda.Stream(device)) for _ in my_streams]
+        ring = [DeviceImage(W, H, nvxcu.NVXCU_DF_IMAGE_RGBX, device).upload(f) for f in host_frames]
+        trackers = [ThinFeatureTracker(params, W, H, device, torch.cuda.Stream(device)) for _ in my_streams]
         for trk, ph in zip(trackers, phases):
             trk.init(ring[ph].desc)
 
         def step(k):
             for trk, ph in zip(trackers, phases):
                 trk.track(ring[(ph + 1 + k) % args.ring].desc)
-
-        def lk_launch_ms():
-            pairs = trackers[0].lk_events or []
-            return (float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else float("nan")), len(pairs)
 
         def counts():
             cur = [trk.curr_features() for trk in trackers]
@@ -210,8 +308,8 @@ def main():
 
     def run(k0, n):
         """n steps (= n frames on every camera stream of this GPU) starting at frame index k0"""
-        if args.api == "ovx" and native:
-            native(k0, n)
+        if driver:
+            ovx.check(drv.vsa_driver_run(driver, k0, n), "vsa_driver_run")
         elif args.api == "ovx" and args.host_threads:
             import threading
             ths = [threading.Thread(target=run_stream, args=(i, k0, n)) for i in range(len(trackers))]
@@ -225,66 +323,111 @@ def main():
 
     run(0, args.warmup)
     torch.cuda.synchronize()
-    barrier(world)
-    if args.api == "thin":
+    if args.api == "ovx":
+        # HIP events around the PyrLK node of stream 0 only (two event records per frame on that graph's stream)
+        ovx.check(L.vxDirective(trackers[0].lk, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
+        if args.homography:
+            ovx.check(L.vxDirective(trackers[0].hg, ovx.VX_DIRECTIVE_ENABLE_PERFORMANCE))
+    else:
         trackers[0].lk_events = []
-    lk_before = lk_launch_ms() if args.api == "ovx" else (0.0, 0)
+    barrier(world)
     t0 = time.perf_counter()
     run(args.warmup, args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier(world)
+    my_elapsed = elapsed
     elapsed = reduce_max(elapsed, world)
+    rank_fps = gather_floats(args.steps * args.streams / my_elapsed, world)
 
-    # PyrLK launch duration from HIP events recorded on its stream during the timed region
-    lk_ms, lk_n = lk_launch_ms()
-    if args.api == "ovx" and lk_n > lk_before[1]:
-        lk_ms = (lk_ms * lk_n - lk_before[0] * lk_before[1]) / (lk_n - lk_before[1])
+    # PyrLK launch duration (HIP events on its stream): (1) over the timed region, where kernels of ~4 streams share the
+    # GPU; (2) alone -- stream 0 driven by itself for 50 frames after the timed region, nothing else on the GPU
+    lk_alone_ms = lk_loaded_ms = float("nan")
+    hg_ms = None
     n_tracks, n_points = counts()
+    if args.api == "ovx":
+        s1, n1 = node_perf(trackers[0].lk)
+        lk_loaded_ms = s1 / max(n1, 1) * 1e-6
+        if args.homography:
+            hs, hn = node_perf(trackers[0].hg)
+            hg_ms = hs / max(hn, 1) * 1e-6
+        solo = make_driver(trackers[:1], phases[:1]) if driver else None
+        k_next = args.warmup + args.steps
+        if solo:
+            ovx.check(drv.vsa_driver_run(solo, k_next, 10), "solo warm-up")
+            s2, n2 = node_perf(trackers[0].lk)
+            ovx.check(drv.vsa_driver_run(solo, k_next + 10, 50), "solo run")
+            drv.vsa_driver_destroy(solo)
+        else:
+            run_stream(0, k_next, 10)
+            s2, n2 = node_perf(trackers[0].lk)
+            run_stream(0, k_next + 10, 50)
+        s3, n3 = node_perf(trackers[0].lk)
+        lk_alone_ms = (s3 - s2) / max(n3 - n2, 1) * 1e-6
+    else:
+        pairs = trackers[0].lk_events or []
+        if pairs:
+            lk_loaded_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
+        trackers[0].lk_events = []
+        for k in range(60):
+            trackers[0].track(ring[(phases[0] + 1 + args.warmup + args.steps + k) % args.ring].desc)
+        torch.cuda.synchronize()
+        lk_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in trackers[0].lk_events[10:]]))
 
     if rank == 0:
+        B = cfg["bytes"]
+        bytes_frame = B["pyramid"] + B["detect"] + B["lk"] + B["cvt"]
         frames = args.steps * args.streams * world
         fps = frames / elapsed
-        lk_gbs = BYTES_LK / (max(lk_ms, 1e-9) * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "lk_hbm_traffic.json")
-        if os.path.exists(tf):
-            with open(tf) as f:
-                traffic = json.load(f).get("bytes_per_launch")
+        lk_gbs = B["lk"] / (max(lk_alone_ms, 1e-9) * 1e-3) / 1e9
+        counters = load_profile_json("frame_counters.json") if args.config == "c2" and not args.homography else None
+        lk_counters = (counters or {}).get("by_kernel", {}).get("k_pyrlk", {})
         out = {
             "metric": "frames/sec @1080p with 4k PyrLK tracks",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD + (" + nvxFindHomographyNode (RANSAC 3.0 px, 56 hypotheses, <=10 refits) on the matches"
-                                               if args.homography else ""), "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
+            "config": {"workload": cfg["workload"] + (" + nvxFindHomographyNode (RANSAC 3.0 px, 56 hypotheses, <=10 refits) on the matches"
+                                                      if args.homography else ""),
+                       "baseline_config": 4 if args.homography else cfg["baseline_config"], "frames": cfg["frames"],
+                       "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
                        "frame_ring": args.ring, "api": api_desc},
+            "per_rank_frames_per_s": rank_fps,
             "tracks_per_sec": fps * float(np.mean(n_tracks)),
             "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),
-            "frame_algorithmic_GBps": BYTES_FRAME * fps / 1e9,
-            "frame_algorithmic_frac_of_hbm_peak": BYTES_FRAME * fps / 1e9 / (HBM_PEAK_GBS * world),
-            "roofline": {"kernel": "k_pyrlk<7,21,true> (PyrLK, 4096 points x 5 levels, 21x21)", "bound": "hbm",
-                         "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "launch_ms": lk_ms, "algorithmic_bytes_per_launch": BYTES_LK},
+            "frame_algorithmic_GBps": bytes_frame * fps / 1e9,
+            "frame_algorithmic_frac_of_hbm_peak": bytes_frame * fps / 1e9 / (HBM_PEAK_GBS * world),
+            # the dominant kernel against the HBM roof.  launch_ms: the kernel ALONE (stream 0 driven by itself after the
+            # timed region, HIP events, 50 launches); launch_ms_in_timed_region: the same events while the other streams'
+            # kernels share the GPU (mean concurrency ~2.3, profiles/r02_bench_concurrency.txt) -- longer, not slower work
+            "roofline": {"kernel": f"{cfg['lk_kernel']} (PyrLK, {cfg['capacity']} points x {cfg['levels']} levels, {cfg['win']}x{cfg['win']})",
+                         "bound": "hbm", "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
+                         "traffic": lk_counters.get("hbm_bytes"), "launch_ms": lk_alone_ms,
+                         "launch_ms_in_timed_region": lk_loaded_ms, "algorithmic_bytes_per_launch": B["lk"]},
         }
-        vf = os.path.join(ROOT, "profiles", "frame_valu_instructions.json")
-        if os.path.exists(vf) and not args.homography:
-            # what actually bounds the path: vector-instruction issue.  Wave-instructions per frame
-            # from the SQ counters, against the f32 FMA issue rate measured on this GPU -- an extra, not the roofline object
-            with open(vf) as f:
-                v = json.load(f)
-            rate = v["wave_instructions_per_frame"] * fps / 1e9 / world
-            out["valu_issue"] = {"wave_instructions_per_frame": v["wave_instructions_per_frame"], "achieved": rate,
-                                 "peak": v["peak_wave_instructions_per_ns"], "unit": "G wave-instructions/s per GPU",
-                                 "frac": rate / v["peak_wave_instructions_per_ns"]}
+        if counters and lk_counters.get("valu_wave_instructions"):
+            # what actually bounds this kernel and the path: vector-instruction issue.  Wave-instructions
+            # from the SQ counters (profiles/frame_counters.json, stamped with the commit they were measured at) against the
+            # f32 FMA issue rate measured on this GPU
+            peak = counters["peak_wave_instructions_per_ns"]
+            lk_rate = lk_counters["valu_wave_instructions"] / (lk_alone_ms * 1e6)
+            out["roofline_valu"] = {"kernel": cfg["lk_kernel"], "bound": "valu issue", "wave_instructions_per_launch": lk_counters["valu_wave_instructions"],
+                                    "achieved": lk_rate, "peak": peak, "unit": "G wave-instructions/s", "frac": lk_rate / peak,
+                                    "launch_ms": lk_alone_ms}
+            per_frame = counters["valu_wave_instructions_per_frame"]
+            rate = per_frame * fps / 1e9 / world
+            out["valu_issue"] = {"wave_instructions_per_frame": per_frame, "achieved": rate, "peak": peak,
+                                 "unit": "G wave-instructions/s per GPU", "frac": rate / peak}
+            out["profiles_commit"] = counters.get("commit")
         if args.homography:
-            perf = ovx.query("vxQueryNode", trackers[0].hg, ovx.VX_NODE_PERFORMANCE, ovx.vx_perf_t)
-            H, mask = trackers[0].homography()
-            out["homography"] = {"node_ms": perf.avg * 1e-6, "inliers_stream0": int((mask != 0).sum()), "points_stream0": int(len(mask)),
-                                 "matrix_stream0": [float(x) for x in H.T.reshape(-1)]}
+            H_, mask = trackers[0].homography()
+            out["homography"] = {"node_ms_in_timed_region": hg_ms, "inliers_stream0": int((mask != 0).sum()), "points_stream0": int(len(mask)),
+                                 "matrix_stream0": [float(x) for x in H_.T.reshape(-1)]}
         if not args.no_cpu_baseline and world == 1 and not args.homography:
             out["cpu_baseline"] = cpu_baseline(host_frames, params)
         print(json.dumps(out), flush=True)
+    if driver:
+        drv.vsa_driver_destroy(driver)
     barrier(world)
     if world > 1:
         import torch.distributed as dist

@@ -56,4 +56,47 @@ def test_single_rank_helpers_need_no_process_group():
     import bench
     assert bench.reduce_max(3.5, 1) == 3.5
     bench.barrier(1)
-    assert bench.BYTES_FRAME == 11138784 + 10368000       # SURVEY 8d table, configs[1]
+    assert bench.gather_floats(2.5, 1) == [2.5]
+    # total algorithmic bytes per frame + the colour convert, per config
+    want = {"c1": 1685700 + 1536000, "c2": 11138784 + 10368000, "c3": 44472360 + 41472000}
+    for name, total in want.items():
+        assert sum(bench.CONFIGS[name]["bytes"].values()) == total
+
+
+def _run_bench(*argv, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=120, env=e)
+    assert res.returncode == 0, res.stdout + res.stderr
+    return [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+
+
+def test_launcher_spawns_one_rank_per_gpu_dry_run():
+    """`python bench.py --gpus N` (the shape of the driver's N=1 command) must not silently measure one GPU: with no
+    launcher around it, it starts the N ranks itself.  --dry-run prints each rank's device and camera streams instead
+    of touching a GPU."""
+    lines = sorted(_run_bench("--gpus", "4", "--streams", "3", "--ring", "8", "--dry-run"), key=lambda d: d["rank"])
+    assert [d["rank"] for d in lines] == [0, 1, 2, 3] and {d["world"] for d in lines} == {4}
+    assert [d["device"] for d in lines] == [0, 1, 2, 3]                              # one GPU per rank
+    assert [d["streams"] for d in lines] == [[0, 4, 8], [1, 5, 9], [2, 6, 10], [3, 7, 11]]   # stream s -> rank s % N
+    assert all(len(d["phases"]) == 3 and all(0 <= ph < 8 for ph in d["phases"]) for d in lines)
+    # a rehearsal on a box with fewer GPUs than ranks: ranks share devices round-robin
+    lines = sorted(_run_bench("--gpus", "4", "--dry-run", "--dry-run-devices", "1"), key=lambda d: d["rank"])
+    assert [d["device"] for d in lines] == [0, 0, 0, 0] and all(len(d["streams"]) == 32 for d in lines)
+    # N = 1 needs no children; the defaults are BASELINE configs[1]'s
+    (one,) = _run_bench("--dry-run")
+    assert one == {"rank": 0, "world": 1, "device": 0, "streams": list(range(32)), "phases": [(3 * s) % 64 for s in range(32)]}
+
+
+def test_torchrun_style_environment_is_respected_dry_run():
+    """under torch.distributed.run the ranks already exist: no children, RANK / LOCAL_RANK / WORLD_SIZE from the environment"""
+    (d,) = _run_bench("--gpus", "2", "--streams", "2", "--dry-run", env=dict(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2"))
+    assert d["rank"] == 1 and d["device"] == 1 and d["streams"] == [1, 3]
+    import subprocess
+    e = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, env=e)
+    assert res.returncode != 0 and "WORLD_SIZE" in res.stderr                         # a mismatch is an error, not a guess
