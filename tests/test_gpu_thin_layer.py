@@ -396,3 +396,53 @@ def test_pyrlk_full_size_config(gpu):
     assert ok.mean() > 0.9
     d = got[ok] - pts[ok]
     assert abs(np.median(d[:, 0]) - 0.8) < 0.05 and abs(np.median(d[:, 1]) - 0.5) < 0.05
+
+
+# --------------------------------------------------------------------------- a C++ caller of the thin layer
+@pytest.mark.parametrize("detector,noalloc,use_mask", [("harris", 0, False), ("fast", 0, True), ("harris", 1, True)])
+def test_cpp_thin_layer_application(gpu, tmp_path, detector, noalloc, use_mask):
+    """visualslam_amd/lib/ftcu_hip (shim/ftcu_hip_main.cpp): the thin-layer application of
+    demos/feature_tracker_nvxcu/feature_tracker_nvxcu.cpp:102-179,255-321,387-484 as a C++ program on HIP -- hipMallocPitch
+    images, device-resident counts, nvxcu_stream_exec_target_t with hipDeviceProp_t filled by hipGetDeviceProperties, one
+    stream synchronisation per frame.  The structs are laid out by the C++ compiler from include/NVX/nvxcu.h, not by
+    ctypes mirrors; every frame's point lists must be the oracle's."""
+    import os
+    import subprocess
+    from oracle.pipeline import OracleTracker
+    from visualslam_amd.thin_tracker import Params
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "visualslam_amd", "lib", "ftcu_hip")
+    assert os.path.exists(exe), "visualslam_amd/lib/ftcu_hip is missing: built by visualslam_amd/csrc/Makefile"
+    w, h, n = 643, 481, 6                      # odd sizes: hipMallocPitch pads the rows, level sizes round up
+    base = synth.base_frame(w, h, 17)
+    frames = [synth.to_rgbx(synth.gray_frame(base, t, 17)) for t in range(n)]
+    fpath, opath = tmp_path / "frames.rgbx", tmp_path / "out.bin"
+    with open(fpath, "wb") as f:
+        for fr in frames:
+            f.write(fr.tobytes())
+    mask = None
+    extra = []
+    if use_mask:
+        mask = _center_mask(w, h)
+        (tmp_path / "mask.u8").write_bytes(mask.tobytes())
+        extra.append(f"mask={tmp_path / 'mask.u8'}")
+    cfg = dict(pyr_levels=5, lk_num_iters=5, lk_win_size=21 if detector == "harris" else 10, array_capacity=1500,
+               detector_cell_size=18, detector=detector, harris_k=0.04, harris_thresh=100.0, fast_type=9, fast_thresh=25, noalloc=noalloc)
+    cmd = [exe, str(fpath), str(w), str(h), str(n), str(opath)] + [f"{k}={v}" for k, v in cfg.items()] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "frames tracked" in res.stdout
+    p = Params(pyr_levels=5, lk_num_iters=5, lk_win_size=cfg["lk_win_size"], array_capacity=1500, detector_cell_size=18,
+               use_harris_detector=detector == "harris", harris_k=0.04, harris_thresh=100.0, fast_type=9, fast_thresh=25)
+    ref = OracleTracker(p)
+    ref.init(frames[0], mask)
+    raw = np.fromfile(opath, np.uint8)
+    off = 0
+    for t in range(1, n):
+        old, cur = ref.track(frames[t], mask)
+        for want in (old, cur):
+            cnt = int(raw[off:off + 4].view(np.uint32)[0]); off += 4
+            got = raw[off:off + 8 * cnt].view(np.float32).reshape(cnt, 2); off += 8 * cnt
+            assert cnt == len(want) and cnt > 100
+            assert got.tobytes() == want.tobytes(), f"frame {t}"
+    assert off == raw.size

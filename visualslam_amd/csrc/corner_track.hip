@@ -413,7 +413,7 @@ __device__ uint64_t g_mg_stamps[16];
 // in that hardware queue) held up meanwhile.  Eight waves of at most 48 VGPRs fit beside a full set of PyrLK waves (2 x 48 =
 // the 96 VGPRs they leave per SIMD): bench 28.4 k -> 30.8 k frames/s, single stream 12.2 k -> 12.0 k.  To stay at 48 VGPRs a wave
 // walks its range in small blocks and re-reads it for the write-out (L2 hits) instead of keeping it in registers
-// (the KEEP form below: 96 VGPRs for 8 + 8 rounds; 512 threads with 8 + 13 rounds in flight and 89 VGPRs: 29.0 k).
+// (a form that kept its ranges in registers between the counting pass and the write-out needed 96 VGPRs and lost 8 %).
 constexpr uint32_t MG_THREADS = 512, MG_WAVES = MG_THREADS / 64;
 // rounds of 64 items per wave and block: tracked points / cells (1080p, cell 18: a wave owns 8 rounds of points, 13 of cells)
 constexpr uint32_t MG_KT = 4, MG_KC = 7;
@@ -503,15 +503,15 @@ __device__ __forceinline__ void emit_corner(const MergeArgs &a, uint32_t pos, ui
 // One workgroup, one pass.  Wave w owns the w-th contiguous range of the tracked points and of the cells and walks
 // it in rounds of 64 consecutive items (lane = item: coalesced loads), so positions follow input order / cell raster
 // order: within a round by the ballot's prefix count, across rounds by a running count, across waves by the wave
-// totals (both lists' totals travel as the two halves of one 64-bit word).  KEEP: every range fits KT / KC rounds,
-// so what was loaded stays in registers for the write-out; otherwise the write-out re-reads (L2 hits).
+// totals (both lists' totals travel as the two halves of one 64-bit word).  The write-out re-reads its ranges (L2 hits)
+// instead of keeping them in registers.
 __device__ __forceinline__ uint32_t lanes_below(uint64_t ballot)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
 }
 
-// KT / KC: rounds of tracked points / cells a wave keeps in registers (KEEP), or the block size of the walks
-template <bool KEEP, uint32_t KT, uint32_t KC>
+// KT / KC: rounds of tracked points / cells per block of a walk (a block's loads are in flight together)
+template <uint32_t KT, uint32_t KC>
 __global__ __launch_bounds__(MG_THREADS) void k_merge_compact(MergeArgs a)
 {
     __shared__ uint64_t wave_tot[MG_WAVES];
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_compact(MergeArgs a)
     // Cells holding a surviving tracked point are marked in LDS, one byte a cell (plain stores: tracked points arrive
     // in cell order, so bits would have the lanes of a wave serialize on the same word with atomic ORs); the keys stay
     // untouched.  Only a cell grid too large for LDS is marked in place, in the keys themselves.
-    const bool in_lds = KEEP || a.flag_words != 0u;
+    const bool in_lds = a.flag_words != 0u;
     for (uint32_t i = tid; i < max(a.flag_words, 1u); i += MG_THREADS) occ_words[i] = 0u;   // word 0 is always there
     const bool has_t = a.tracked != nullptr && a.tracked_capacity != 0u;
     const uint32_t cap_t = has_t ? a.tracked_capacity : 0u;
@@ -533,41 +533,26 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_compact(MergeArgs a)
     asm volatile("" : "+v"(zero));
     const uint32_t nt = has_t ? min(a.tracked_count[zero], cap_t) : 0u;
     const uint32_t ncells = (uint32_t)a.ncx * (uint32_t)a.ncy;
-    // range sizes come from the capacity, not the live count, so KEEP is a launch-time decision
+    // range sizes come from the capacity, not the live count
     const uint32_t rounds_t = (cap_t + MG_THREADS - 1) / MG_THREADS, rounds_c = (ncells + MG_THREADS - 1) / MG_THREADS;
     const uint32_t tbase = wave * rounds_t * 64u + lane, cbase = wave * rounds_c * 64u + lane;
 
     // phase 0: cells holding a surviving tracked point emit no new corner
-    uint32_t n_alive = 0, alive_bits = 0;
-    float px[KEEP ? KT : 1], py[KEEP ? KT : 1];
-    uint64_t key[KEEP ? KC : 1];
-    if constexpr (KEEP) {
-        keys_fetch<KC>(a, cbase, 0u, rounds_c, ncells, key);    // in flight together with the points
-        if (has_t) alive_bits = tracked_fetch<KT>(a, tbase, 0u, rounds_t, nt, px, py);
-        __syncthreads();      // flags cleared
-        MG_STAMP(1);
+    uint32_t n_alive = 0;
+    __syncthreads();      // flags cleared
+    MG_STAMP(1);
+    for (uint32_t r0 = 0; has_t && r0 < rounds_t; r0 += KT) {   // blocks of KT rounds: the loads of a block are in flight together
+        float x[KT], y[KT];
+        const uint32_t bits = tracked_fetch<KT>(a, tbase + r0 * 64u, r0, rounds_t, nt, x, y);
 #pragma unroll
         for (uint32_t r = 0; r < KT; ++r) {
-            const bool alive = (alive_bits >> r) & 1u;
-            if (alive) occ[cell_of(a, px[r], py[r])] = 1;
-            n_alive += (uint32_t)__popcll(__ballot(alive));
-        }
-    } else {   // blocks of KT rounds: the loads of a block are in flight together
-        __syncthreads();      // flags cleared
-        MG_STAMP(1);
-        for (uint32_t r0 = 0; has_t && r0 < rounds_t; r0 += KT) {
-            float x[KT], y[KT];
-            const uint32_t bits = tracked_fetch<KT>(a, tbase + r0 * 64u, r0, rounds_t, nt, x, y);
-#pragma unroll
-            for (uint32_t r = 0; r < KT; ++r) {
-                const bool alive = (bits >> r) & 1u;
-                if (alive) {
-                    const uint32_t cell = cell_of(a, x[r], y[r]);
-                    if (in_lds) occ[cell] = 1;
-                    else a.cell_best[cell] = OCCUPIED;
-                }
-                n_alive += (uint32_t)__popcll(__ballot(alive));
+            const bool alive = (bits >> r) & 1u;
+            if (alive) {
+                const uint32_t cell = cell_of(a, x[r], y[r]);
+                if (in_lds) occ[cell] = 1;
+                else a.cell_best[cell] = OCCUPIED;
             }
+            n_alive += (uint32_t)__popcll(__ballot(alive));
         }
     }
     MG_STAMP(2);
@@ -582,16 +567,11 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_compact(MergeArgs a)
         return (k != 0ull) & (k != OCCUPIED) & (marked == 0u);
     };
     uint32_t n_new = 0;
-    if constexpr (KEEP) {
+    for (uint32_t r0 = 0; r0 < rounds_c; r0 += KC) {
+        uint64_t k[KC];
+        keys_fetch<KC>(a, cbase + r0 * 64u, r0, rounds_c, ncells, k);
 #pragma unroll
-        for (uint32_t r = 0; r < KC; ++r) n_new += (uint32_t)__popcll(__ballot(fresh_key(key[r], cbase + r * 64u)));
-    } else {
-        for (uint32_t r0 = 0; r0 < rounds_c; r0 += KC) {
-            uint64_t k[KC];
-            keys_fetch<KC>(a, cbase + r0 * 64u, r0, rounds_c, ncells, k);
-#pragma unroll
-            for (uint32_t r = 0; r < KC; ++r) n_new += (uint32_t)__popcll(__ballot(fresh_key(k[r], cbase + (r0 + r) * 64u)));
-        }
+        for (uint32_t r = 0; r < KC; ++r) n_new += (uint32_t)__popcll(__ballot(fresh_key(k[r], cbase + (r0 + r) * 64u)));
     }
 
     // the counts are wave-uniform: exclusive scan over the wave totals
@@ -610,45 +590,27 @@ __global__ __launch_bounds__(MG_THREADS) void k_merge_compact(MergeArgs a)
 
     uint32_t pos = (uint32_t)wave_off;                              // survivors, input order
     uint32_t cpos = total_alive + (uint32_t)(wave_off >> 32);       // new corners, cell raster order
-    if constexpr (KEEP) {
+    for (uint32_t r0 = 0; has_t && r0 < rounds_t; r0 += KT) {
+        float x[KT], y[KT];
+        const uint32_t bits = tracked_fetch<KT>(a, tbase + r0 * 64u, r0, rounds_t, nt, x, y);
 #pragma unroll
         for (uint32_t r = 0; r < KT; ++r) {
-            const bool alive = (alive_bits >> r) & 1u;
+            const bool alive = (bits >> r) & 1u;
             const uint64_t b = __ballot(alive);
-            if (alive) emit_survivor(a, pos + lanes_below(b), tbase + r * 64u, px[r], py[r]);
+            if (alive) emit_survivor(a, pos + lanes_below(b), tbase + (r0 + r) * 64u, x[r], y[r]);
             pos += (uint32_t)__popcll(b);
         }
-        MG_STAMP(7);
+    }
+    MG_STAMP(7);
+    for (uint32_t r0 = 0; r0 < rounds_c; r0 += KC) {
+        uint64_t k[KC];
+        keys_fetch<KC>(a, cbase + r0 * 64u, r0, rounds_c, ncells, k);
 #pragma unroll
         for (uint32_t r = 0; r < KC; ++r) {
-            const bool fresh = fresh_key(key[r], cbase + r * 64u);
+            const bool fresh = fresh_key(k[r], cbase + (r0 + r) * 64u);
             const uint64_t b = __ballot(fresh);
-            if (fresh) emit_corner(a, cpos + lanes_below(b), key[r]);
+            if (fresh) emit_corner(a, cpos + lanes_below(b), k[r]);
             cpos += (uint32_t)__popcll(b);
-        }
-    } else {
-        for (uint32_t r0 = 0; has_t && r0 < rounds_t; r0 += KT) {
-            float x[KT], y[KT];
-            const uint32_t bits = tracked_fetch<KT>(a, tbase + r0 * 64u, r0, rounds_t, nt, x, y);
-#pragma unroll
-            for (uint32_t r = 0; r < KT; ++r) {
-                const bool alive = (bits >> r) & 1u;
-                const uint64_t b = __ballot(alive);
-                if (alive) emit_survivor(a, pos + lanes_below(b), tbase + (r0 + r) * 64u, x[r], y[r]);
-                pos += (uint32_t)__popcll(b);
-            }
-        }
-        MG_STAMP(7);
-        for (uint32_t r0 = 0; r0 < rounds_c; r0 += KC) {
-            uint64_t k[KC];
-            keys_fetch<KC>(a, cbase + r0 * 64u, r0, rounds_c, ncells, k);
-#pragma unroll
-            for (uint32_t r = 0; r < KC; ++r) {
-                const bool fresh = fresh_key(k[r], cbase + (r0 + r) * 64u);
-                const uint64_t b = __ballot(fresh);
-                if (fresh) emit_corner(a, cpos + lanes_below(b), k[r]);
-                cpos += (uint32_t)__popcll(b);
-            }
         }
     }
     MG_STAMP(6);
@@ -721,12 +683,10 @@ hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream)
     m.w = a.w; m.h = a.h; m.cs = a.cs; m.ncx = a.ncx; m.ncy = a.ncy;
     const uint32_t ncells = (uint32_t)a.ncx * (uint32_t)a.ncy;
     if (ncells == 0u) return hipErrorInvalidValue;
-    const uint32_t cap_t = p.tracked ? p.tracked_capacity : 0u;
     m.flag_words = ncells <= 60u * 1024u ? (ncells + 3u) / 4u : 0u;   // beyond 60 K cells the keys are marked in place
     const size_t lds = (size_t)(m.flag_words ? m.flag_words : 1u) * 4u;
     m.cs_magic = cs > 1u ? (uint32_t)((0x100000000ull + cs - 1u) / cs) : 0u;
-    (void)cap_t;
-    hipLaunchKernelGGL((k_merge_compact<false, MG_KT, MG_KC>), dim3(1), dim3(MG_THREADS), lds, stream, m);
+    hipLaunchKernelGGL((k_merge_compact<MG_KT, MG_KC>), dim3(1), dim3(MG_THREADS), lds, stream, m);
     return hipGetLastError();
 }
 

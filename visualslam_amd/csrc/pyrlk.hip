@@ -476,11 +476,18 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         if (a.item == kPoint2f) {
             reinterpret_cast<float2 *>(a.out)[pi] = ok ? make_float2(rx, ry) : make_float2(-1.0f, -1.0f);
         } else {
-            KeypointF o = reinterpret_cast<const KeypointF *>(a.prev_pts)[pi];
-            o.error = ok ? err : 0.0f;
-            if (ok) { o.x = rx; o.y = ry; o.tracking_status = 255; }
-            else    { o.x = ex; o.y = ey; o.tracking_status = 0; }
-            reinterpret_cast<KeypointF *>(a.out)[pi] = o;
+            // field by field: a struct copy is lowered through a private-memory temporary, which leaves the kernel
+            // with a 16-byte scratch allocation per lane although no instruction ever touches it
+            const KeypointF *src = reinterpret_cast<const KeypointF *>(a.prev_pts) + pi;
+            KeypointF *dst = reinterpret_cast<KeypointF *>(a.out) + pi;
+            const float strength = src->strength, scale = src->scale, orientation = src->orientation;
+            dst->x = ok ? rx : ex;
+            dst->y = ok ? ry : ey;
+            dst->strength = strength;
+            dst->scale = scale;
+            dst->orientation = orientation;
+            dst->tracking_status = ok ? 255 : 0;
+            dst->error = ok ? err : 0.0f;
         }
     }
 #ifdef VSA_LK_STAMPS
