@@ -6,13 +6,14 @@
 // demos/video_stabilizer/homography_filter_node.cpp:36-159.  Semantics and the exact floating-point order:
 // oracle/vxoracle_homography.c -- results are bit-identical.
 //
-// Two launches, no host round trip:
-//   k_hg_hypotheses  one workgroup per hypothesis (all hypotheses of the a-priori RANSAC count are independent, so
-//                    they run as one batch): wave 0 draws the 4-point sample and maps it exactly in binary64 while
-//                    the other waves fetch points; the workgroup then counts the hypothesis' inliers (binary32);
-//   k_hg_refine      one workgroup: picks the best hypothesis, normalises coordinates, then alternates
-//                    least-squares refits (29 binary64 sums in 256 interleaved partials + butterfly, 8x8 LDL^T)
-//                    with inlier recounts; writes matrix, mask and counts (also to pinned mirrors).
+// One launch, no host round trip (k_find_homography):
+//   * workgroup k evaluates hypothesis k (all hypotheses of the a-priori RANSAC count are independent, so they run as
+//     one batch): wave 0 draws the 4-point sample and maps it exactly in binary64 while the other waves fetch points;
+//     the workgroup then counts the hypothesis' inliers (binary32, division-free) and publishes count and matrix;
+//   * the workgroup that takes the last ticket (device-scope release / acquire) goes on with its points still in
+//     registers: it picks the best hypothesis, normalises coordinates, then alternates least-squares refits (29 binary64
+//     sums in 256 interleaved partials + butterfly, 8x8 LDL^T) with inlier recounts; writes matrix, mask and counts
+//     (also to pinned mirrors).
 // The work is tiny (56 x 4096 point tests): latency, not throughput, is what matters.  Hence
 //   * NPT > 0 variants, used when the arrays' capacities bound the point count by NPT*256: every point stays in
 //     registers for the whole kernel, and the loads do not wait for the item counts (NPT = 0: any size, global loads);
