@@ -12,11 +12,11 @@
 namespace vsa {
 namespace {
 
-__device__ __forceinline__ uint32_t luma709(uint32_t rgbx)
-{
-    const uint32_t r = rgbx & 0xffu, g = (rgbx >> 8) & 0xffu, b = (rgbx >> 16) & 0xffu;
-    return (54u * r + 183u * g + 19u * b + 128u) >> 8;
-}
+// (54 R + 183 G + 19 B + 128) >> 8 as one byte-wise dot product (v_dot4_u32_u8: bytes R, G, B, X against 54, 183, 19, 0,
+// accumulated onto the rounding constant) and a shift -- two instructions a pixel instead of three field extractions
+// and three multiply-adds
+__device__ __forceinline__ uint32_t luma709_x256(uint32_t rgbx) { return __builtin_amdgcn_udot4(rgbx, 0x0013B736u, 128u, false); }
+__device__ __forceinline__ uint32_t luma709(uint32_t rgbx) { return luma709_x256(rgbx) >> 8; }
 
 // 4 pixels per lane: one 16-byte load, one 4-byte store.  A wave moves 1 KiB in / 256 B out per
 // instruction pair.  Requires 16-B aligned source rows and 4-B aligned destination rows.
@@ -32,8 +32,10 @@ __global__ __launch_bounds__(256) void k_rgbx_to_u8_vec(const uint8_t *__restric
     uint8_t *d = dst + (size_t)y * dp + x;
     if (x + 4u <= w) {
         const uint4 v = *reinterpret_cast<const uint4 *>(s);
-        const uint32_t o = luma709(v.x) | (luma709(v.y) << 8) | (luma709(v.z) << 16) | (luma709(v.w) << 24);
-        *reinterpret_cast<uint32_t *>(d) = o;
+        // byte 1 of each 16-bit sum is the luma: two byte permutes gather the four of them
+        const uint32_t lo = __builtin_amdgcn_perm(luma709_x256(v.y), luma709_x256(v.x), 0x0c0c0501u);
+        const uint32_t hi = __builtin_amdgcn_perm(luma709_x256(v.w), luma709_x256(v.z), 0x05010c0cu);
+        *reinterpret_cast<uint32_t *>(d) = lo | hi;
     } else {
         for (uint32_t i = 0; x + i < w; ++i)
             d[i] = (uint8_t)luma709(reinterpret_cast<const uint32_t *>(s)[i]);
@@ -80,43 +82,74 @@ struct PyrFusedArgs {
 
 constexpr int pyr_pow2_at_least(int n) { return n <= 1 ? 1 : 2 * pyr_pow2_at_least((n + 1) / 2); }
 
-// A thread keeps one destination column for the whole step (CW = RD rounded up to a power of two columns per row of
-// threads, so row and column are a shift and a mask of the thread index and everything that depends on the column
-// only -- the replicate clamp, the source offset, the ownership test -- is computed once); rows advance by a fixed
-// stride.  Per output that leaves the five LDS reads, four multiply-adds and the store.
+// LDS layout of a step: the source tile has a row stride SS that is a multiple of 4 (so the byte offset of a column
+// inside its dword is the same in every row), the destination tile a stride SD = pyr_stride(RD), the intermediate
+// (horizontal sums, u16, at most 16 * 255) a stride TD = RD rounded up to even so that two columns share a dword.
+// Rows past a tile's last column hold values nobody uses (finite garbage is fine: all arithmetic is integer and the
+// packed halves are independent).
+constexpr int pyr_stride(int rd) { return (rd + 3) / 4 * 4; }
+constexpr int pyr_tstride(int rd) { return (rd + 1) / 2 * 2; }
+
+typedef unsigned short pyr_u16x2 __attribute__((ext_vector_type(2)));
+
+// One HALF step, LDS -> LDS (+ the owned pixels to global memory).
+//   horizontal: a thread keeps one destination column (the replicate clamp, the source dword and the byte offset
+//     inside it are computed once); per row TWO aligned dwords (one ds_read2_b32) hold the five taps, v_alignbyte
+//     brings the first four into one register and v_dot4_u32_u8 weighs them 1 4 6 4 with the fifth as the accumulator:
+//     1 LDS read and 3 vector instructions per value (it was 5 byte reads and 4 multiply-adds);
+//   vertical: a thread keeps a PAIR of destination columns; five dword reads of the u16 sums and packed 16-bit
+//     arithmetic (the total, 16 * 16 * 255 + 128, still fits 16 bits) give two pixels.
+// Every value is the exact integer the oracle computes: (sum of the 25 weighted taps + 128) >> 8.
 template <int RS, int SS, int RD>
 __device__ __forceinline__ void pyr_step(const uint8_t *src, int soff, int sox, int soy,
                                          uint8_t *dstl, int dox, int doy, int dw, int dh,
                                          uint16_t *tmp, uint8_t *gdst, uint32_t gpitch,
                                          int own_x0, int own_y0, int own_n, int tid)
 {
-    constexpr int CW = pyr_pow2_at_least(RD) < PYR_THREADS ? pyr_pow2_at_least(RD) : PYR_THREADS;
-    constexpr int RSTEP = PYR_THREADS / CW;
-    const int c = tid & (CW - 1), r0 = tid / CW;
-    const int X = dox + c;
-    const bool col = c < RD;
-    // horizontal: every source-region row, every destination column
-    {
-        const int xc = min(max(X, 0), dw - 1);
-        const uint8_t *p = src + r0 * SS + soff + (2 * xc - 2 - sox);
-        uint16_t *t = tmp + r0 * RD + c;
-        if (col)
-            for (int r = r0; r < RS; r += RSTEP, p += RSTEP * SS, t += RSTEP * RD)
-                *t = (uint16_t)(p[0] + 4 * p[1] + 6 * p[2] + 4 * p[3] + p[4]);
+    static_assert(SS % 4 == 0, "source rows start on dword boundaries");
+    constexpr int SD = pyr_stride(RD), TD = pyr_tstride(RD);
+    {   // horizontal: every source-region row, every destination column
+        constexpr int CW = pyr_pow2_at_least(RD) < PYR_THREADS ? pyr_pow2_at_least(RD) : PYR_THREADS;
+        constexpr int RSTEP = PYR_THREADS / CW;
+        const int c = tid & (CW - 1), r0 = tid / CW;
+        const int xc = min(max(dox + c, 0), dw - 1);
+        const int A = soff + (2 * xc - 2 - sox);                 // byte offset of the first tap inside a row
+        const uint32_t shift = (uint32_t)A & 3u;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(src + r0 * SS + (A & ~3));
+        uint16_t *t = tmp + r0 * TD + c;
+        if (c < RD)
+            for (int r = r0; r < RS; r += RSTEP, p += RSTEP * (SS / 4), t += RSTEP * TD) {
+                const uint32_t lo = p[0], hi = p[1];
+                const uint32_t taps = __builtin_amdgcn_alignbyte(hi, lo, shift);          // taps 0..3
+                const uint32_t last = __builtin_amdgcn_ubfe(hi, 8u * shift, 8u);          // tap 4
+                *t = (uint16_t)__builtin_amdgcn_udot4(taps, 0x04060401u, last, false);
+            }
     }
     __syncthreads();
-    {
-        const bool own_col = col && X >= own_x0 && X < own_x0 + own_n && X < dw;
+    {   // vertical: every destination row, pairs of destination columns
+        constexpr int NP = TD / 2;
+        constexpr int CW = pyr_pow2_at_least(NP) < PYR_THREADS ? pyr_pow2_at_least(NP) : PYR_THREADS;
+        constexpr int RSTEP = PYR_THREADS / CW;
+        const int cp = tid & (CW - 1), r0 = tid / CW;
+        const int X0 = dox + 2 * cp;
+        const bool own0 = X0 >= own_x0 && X0 < own_x0 + own_n && X0 < dw && 2 * cp < RD;
+        const bool own1 = X0 + 1 >= own_x0 && X0 + 1 < own_x0 + own_n && X0 + 1 < dw && 2 * cp + 1 < RD;
         const int y_end = min(own_y0 + own_n, dh);
-        if (col)
+        const pyr_u16x2 *tw = reinterpret_cast<const pyr_u16x2 *>(tmp) + cp;
+        if (cp < NP)
             for (int y = r0; y < RD; y += RSTEP) {
                 const int Y = doy + y;
                 const int yc = min(max(Y, 0), dh - 1);
-                const uint16_t *t = tmp + (2 * yc - 2 - soy) * RD + c;
-                const uint32_t s = t[0] + 4u * t[RD] + 6u * t[2 * RD] + 4u * t[3 * RD] + t[4 * RD];
-                const uint8_t v = (uint8_t)((s + 128u) >> 8);
-                dstl[y * RD + c] = v;
-                if (own_col && Y >= own_y0 && Y < y_end) gdst[(size_t)Y * gpitch + X] = v;
+                const pyr_u16x2 *t = tw + (2 * yc - 2 - soy) * NP;
+                pyr_u16x2 sum = (t[0] + t[4 * NP]) + (t[NP] + t[3 * NP]) * (unsigned short)4 + t[2 * NP] * (unsigned short)6;
+                sum = (sum + (unsigned short)128) >> (unsigned short)8;
+                const uint32_t v0 = sum.x, v1 = sum.y;
+                *reinterpret_cast<uint16_t *>(dstl + y * SD + 2 * cp) = (uint16_t)(v0 | (v1 << 8));
+                if (Y >= own_y0 && Y < y_end) {
+                    uint8_t *g = gdst + (size_t)Y * gpitch + X0;
+                    if (own0) g[0] = (uint8_t)v0;
+                    if (own1) g[1] = (uint8_t)v1;
+                }
             }
     }
     __syncthreads();
@@ -134,12 +167,13 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_fused(PyrFusedArgs a)
     constexpr int S0 = (R0 + 3 + 3) / 4 * 4;          // aligned-dword row stride of the source region
     constexpr int ND = S0 / 4;
 
-    __shared__ __attribute__((aligned(16))) uint8_t l0[R0 * S0];
-    __shared__ uint8_t l1[R1 * R1];
-    __shared__ uint8_t l2[R2 * R2];
-    __shared__ uint8_t l3[R3 * R3];
-    __shared__ uint8_t l4[R4 * R4];
-    __shared__ uint16_t tmp[R0 * R1];
+    // + 8: the two-dword reads of the last row's last columns may run a few bytes past the tile
+    __shared__ __attribute__((aligned(16))) uint8_t l0[R0 * S0 + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t l1[R1 * pyr_stride(R1) + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t l2[R2 * pyr_stride(R2) + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t l3[R3 * pyr_stride(R3) + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t l4[R4 * pyr_stride(R4) + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t tmp[R0 * pyr_tstride(R1)];
 
     const int tid = threadIdx.x;
     int ox[5], oy[5];
@@ -189,13 +223,13 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_fused(PyrFusedArgs a)
     pyr_step<R0, S0, R1>(l0, off, ox[0], oy[0], l1, ox[1], oy[1], a.dw[0], a.dh[0], tmp, a.dst[0], a.dst_pitch[0],
                          ox[NS] << (NS - 1), oy[NS] << (NS - 1), T << (NS - 1), tid);
     if (NS >= 2)
-        pyr_step<R1, R1, R2>(l1, 0, ox[1], oy[1], l2, ox[2], oy[2], a.dw[1], a.dh[1], tmp, a.dst[1], a.dst_pitch[1],
+        pyr_step<R1, pyr_stride(R1), R2>(l1, 0, ox[1], oy[1], l2, ox[2], oy[2], a.dw[1], a.dh[1], tmp, a.dst[1], a.dst_pitch[1],
                              ox[NS] << (NS - 2), oy[NS] << (NS - 2), T << (NS - 2), tid);
     if (NS >= 3)
-        pyr_step<R2, R2, R3>(l2, 0, ox[2], oy[2], l3, ox[3], oy[3], a.dw[2], a.dh[2], tmp, a.dst[2], a.dst_pitch[2],
+        pyr_step<R2, pyr_stride(R2), R3>(l2, 0, ox[2], oy[2], l3, ox[3], oy[3], a.dw[2], a.dh[2], tmp, a.dst[2], a.dst_pitch[2],
                              ox[NS] << (NS - 3), oy[NS] << (NS - 3), T << (NS - 3), tid);
     if (NS >= 4)
-        pyr_step<R3, R3, R4>(l3, 0, ox[3], oy[3], l4, ox[4], oy[4], a.dw[3], a.dh[3], tmp, a.dst[3], a.dst_pitch[3],
+        pyr_step<R3, pyr_stride(R3), R4>(l3, 0, ox[3], oy[3], l4, ox[4], oy[4], a.dw[3], a.dh[3], tmp, a.dst[3], a.dst_pitch[3],
                              ox[NS], oy[NS], T, tid);
 }
 
