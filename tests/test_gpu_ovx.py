@@ -391,3 +391,61 @@ def test_native_host_threads_drive_streams_like_the_python_loop(ctx):
                                arr([t.pyr_delay for t in trackers[:2]]), arr([t.pts_delay for t in trackers[:2]]), arr(ring), ring_len,
                                (C.c_int * 2)(0, 1), 0, 1)
     assert st == ovx.VX_ERROR_INVALID_REFERENCE
+
+
+@pytest.mark.parametrize("w,h,levels", [(640, 480, 6), (643, 481, 5), (1920, 1080, 5), (3840, 2160, 7), (37, 29, 3), (130, 70, 2),
+                                        (5, 3, 2), (64, 64, 1)])
+@pytest.mark.parametrize("fusion", [True, False])
+def test_color_convert_and_pyramid_nodes_fused_or_not(gpu, monkeypatch, w, h, levels, fusion):
+    """vxVerifyGraph fuses ColorConvert(frame -> level 0) with GaussianPyramid(level 0 -> pyramid) into one launch that reads
+    the RGBX frame (the first two nodes of the tracker graphs, feature_tracker.cpp:386,393); VISUALSLAM_AMD_NO_FUSION
+    keeps them apart.  Either way every level is the oracle's, bit for bit, also after the frame is rebound."""
+    if not fusion:
+        monkeypatch.setenv("VISUALSLAM_AMD_NO_FUSION", "1")
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    try:
+        frames = [synth.color_rgbx(w, h, seed=w + 3 * h + k) for k in range(2)]
+        imgs = []
+        for f in frames:
+            img = L.vxCreateImage(c, w, h, ovx.VX_DF_IMAGE_RGBX)
+            ovx.write_image(img, f)
+            imgs.append(img)
+        pyr = L.vxCreatePyramid(c, levels, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
+        gray = L.vxGetPyramidLevel(pyr, 0)
+        g = L.vxCreateGraph(c)
+        pn = L.vxGaussianPyramidNode(g, gray, pyr)          # created first: the order comes from the data
+        cn = L.vxColorConvertNode(g, imgs[0], gray)
+        assert L.vxGetStatus(pn) == ovx.VX_SUCCESS and L.vxGetStatus(cn) == ovx.VX_SUCCESS
+        ovx.check(L.vxVerifyGraph(g), "vxVerifyGraph")
+        for k in (0, 1, 0):
+            ovx.check(L.vxSetParameterByIndex(cn, 0, imgs[k]))
+            assert L.vxIsGraphVerified(g) == 1
+            ovx.check(L.vxProcessGraph(g), "vxProcessGraph")
+            want = O.gaussian_pyramid(O.color_convert(frames[k]), levels)
+            for lvl in range(levels):
+                li = L.vxGetPyramidLevel(pyr, lvl)
+                np.testing.assert_array_equal(ovx.read_image(li), want[lvl], err_msg=f"frame {k} level {lvl}")
+                ovx.release("Image", li)
+    finally:
+        assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
+
+
+def test_fusion_is_skipped_when_a_node_reads_the_grey_image_before_the_pyramid(ctx):
+    """a node ordered between ColorConvert and GaussianPyramid that reads level 0 must see the converted frame"""
+    w, h = 96, 64
+    f = synth.color_rgbx(w, h, seed=3)
+    img = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+    ovx.write_image(img, f)
+    pyr = L.vxCreatePyramid(ctx, 3, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
+    gray = L.vxGetPyramidLevel(pyr, 0)
+    copy = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
+    g = L.vxCreateGraph(ctx)
+    L.vxColorConvertNode(g, img, gray)
+    L.nvxCopyImageNode(g, gray, copy)                       # created (and therefore ordered) before the pyramid node
+    L.vxGaussianPyramidNode(g, gray, pyr)
+    ovx.check(L.vxProcessGraph(g), "vxProcessGraph")
+    want = O.gaussian_pyramid(O.color_convert(f), 3)
+    np.testing.assert_array_equal(ovx.read_image(copy), want[0])
+    lv2 = L.vxGetPyramidLevel(pyr, 2)
+    np.testing.assert_array_equal(ovx.read_image(lv2), want[2])

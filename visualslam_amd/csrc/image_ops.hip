@@ -17,6 +17,13 @@ namespace {
 // and three multiply-adds
 __device__ __forceinline__ uint32_t luma709_x256(uint32_t rgbx) { return __builtin_amdgcn_udot4(rgbx, 0x0013B736u, 128u, false); }
 __device__ __forceinline__ uint32_t luma709(uint32_t rgbx) { return luma709_x256(rgbx) >> 8; }
+// four pixels -> four luma bytes: byte 1 of each 16-bit sum is the luma, two byte permutes gather them
+__device__ __forceinline__ uint32_t luma709_x4(uint4 v)
+{
+    const uint32_t lo = __builtin_amdgcn_perm(luma709_x256(v.y), luma709_x256(v.x), 0x0c0c0501u);
+    const uint32_t hi = __builtin_amdgcn_perm(luma709_x256(v.w), luma709_x256(v.z), 0x05010c0cu);
+    return lo | hi;
+}
 
 // 4 pixels per lane: one 16-byte load, one 4-byte store.  A wave moves 1 KiB in / 256 B out per
 // instruction pair.  Requires 16-B aligned source rows and 4-B aligned destination rows.
@@ -32,10 +39,7 @@ __global__ __launch_bounds__(256) void k_rgbx_to_u8_vec(const uint8_t *__restric
     uint8_t *d = dst + (size_t)y * dp + x;
     if (x + 4u <= w) {
         const uint4 v = *reinterpret_cast<const uint4 *>(s);
-        // byte 1 of each 16-bit sum is the luma: two byte permutes gather the four of them
-        const uint32_t lo = __builtin_amdgcn_perm(luma709_x256(v.y), luma709_x256(v.x), 0x0c0c0501u);
-        const uint32_t hi = __builtin_amdgcn_perm(luma709_x256(v.w), luma709_x256(v.z), 0x05010c0cu);
-        *reinterpret_cast<uint32_t *>(d) = lo | hi;
+        *reinterpret_cast<uint32_t *>(d) = luma709_x4(v);
     } else {
         for (uint32_t i = 0; x + i < w; ++i)
             d[i] = (uint8_t)luma709(reinterpret_cast<const uint32_t *>(s)[i]);
@@ -78,6 +82,10 @@ struct PyrFusedArgs {
     uint32_t dst_pitch[4];
     int dw[4], dh[4];
     int aligned;    // src base and pitch are multiples of 4
+    // RGBX variants only: the colour frame level 0 is made from (16-byte aligned base and pitch, rows readable up to the
+    // next multiple of 4 pixels); `src` is then level 0 as an OUTPUT (4-byte aligned), written by the tiles that own it
+    const uint8_t *rgbx;
+    uint32_t rgbx_pitch;
 };
 
 constexpr int pyr_pow2_at_least(int n) { return n <= 1 ? 1 : 2 * pyr_pow2_at_least((n + 1) / 2); }
@@ -155,7 +163,12 @@ __device__ __forceinline__ void pyr_step(const uint8_t *src, int soff, int sox, 
     __syncthreads();
 }
 
-template <int NS, int T>
+// RGBX: the launch also IS the colour convert -- the source region is fetched from the RGBX frame (16 bytes = 4 pixels
+// per load), turned into luma on the way into LDS, and every tile stores the part of level 0 it owns.  One launch less
+// per frame: on this workload the four hardware queues run their streams' kernels back to back with ~4.5 us between two
+// kernels, so a launch costs ~4 % of the frame rate whatever it computes (profiles/r02_kernel_experiments.txt), against
+// which the luma of the halos being computed by several tiles is cheap.
+template <int NS, int T, bool RGBX>
 __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_fused(PyrFusedArgs a)
 {
     VSA_SHORT_KERNEL_PRIORITY();
@@ -186,22 +199,52 @@ __global__ __launch_bounds__(PYR_THREADS) void k_pyramid_fused(PyrFusedArgs a)
 
     // source region
     const int xa = ox[0] & ~3, off = ox[0] - xa;
-    if (a.aligned) {
+    if (RGBX || a.aligned) {
         uint32_t *l0w = reinterpret_cast<uint32_t *>(l0);
         const int xmax = (a.sw - 1) & ~3;
         constexpr int NLD = (R0 * ND + PYR_THREADS - 1) / PYR_THREADS;
-        uint32_t v[NLD];
+        if (RGBX) {
+            uint4 v[NLD];
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {   // all loads in flight before the first LDS write
-            const int i = min(tid + k * PYR_THREADS, R0 * ND - 1);
-            const int r = i / ND, d = i % ND;
-            const int gy = min(max(oy[0] + r, 0), a.sh - 1);
-            const int X = min(max(xa + 4 * d, 0), xmax);
-            v[k] = *reinterpret_cast<const uint32_t *>(a.src + (size_t)gy * a.src_pitch + X);
+            for (int k = 0; k < NLD; ++k) {   // all loads in flight before the first LDS write
+                const int i = min(tid + k * PYR_THREADS, R0 * ND - 1);
+                const int r = i / ND, d = i % ND;
+                const int gy = min(max(oy[0] + r, 0), a.sh - 1);
+                const int X = min(max(xa + 4 * d, 0), xmax);
+                v[k] = *reinterpret_cast<const uint4 *>(a.rgbx + (size_t)gy * a.rgbx_pitch + 4 * (size_t)X);
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) l0w[min(tid + k * PYR_THREADS, R0 * ND - 1)] = luma709_x4(v[k]);
+            __syncthreads();
+            // level 0 itself: the T << NS square this tile owns, as dwords (its first column is a multiple of 4 both in
+            // the image and in the region: ox[0] = own_x0 - (2^(NS+1) - 2), xa = ox[0] - 2)
+            constexpr int OWN = T << NS, OD = OWN / 4;
+            const int own_x0 = ox[NS] << NS, own_y0 = oy[NS] << NS;
+            const int dcol = (own_x0 - xa) / 4, rrow = own_y0 - oy[0];
+            uint8_t *lvl0 = const_cast<uint8_t *>(a.src);
+            for (int i = tid; i < OWN * OD; i += PYR_THREADS) {
+                const int r = i / OD, d = i % OD;
+                const int Y = own_y0 + r, X = own_x0 + 4 * d;
+                if (Y >= a.sh || X >= a.sw) continue;
+                const uint32_t px = l0w[(rrow + r) * ND + dcol + d];
+                uint8_t *g = lvl0 + (size_t)Y * a.src_pitch + X;
+                if (X + 4 <= a.sw) *reinterpret_cast<uint32_t *>(g) = px;
+                else for (int b = 0; X + b < a.sw; ++b) g[b] = (uint8_t)(px >> (8 * b));
+            }
+        } else {
+            uint32_t v[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {   // all loads in flight before the first LDS write
+                const int i = min(tid + k * PYR_THREADS, R0 * ND - 1);
+                const int r = i / ND, d = i % ND;
+                const int gy = min(max(oy[0] + r, 0), a.sh - 1);
+                const int X = min(max(xa + 4 * d, 0), xmax);
+                v[k] = *reinterpret_cast<const uint32_t *>(a.src + (size_t)gy * a.src_pitch + X);
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) l0w[min(tid + k * PYR_THREADS, R0 * ND - 1)] = v[k];
+            __syncthreads();
         }
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) l0w[min(tid + k * PYR_THREADS, R0 * ND - 1)] = v[k];
-        __syncthreads();
         if (ox[0] < 0 || ox[0] + R0 > a.sw) {   // replicate the columns outside the image
             for (int i = tid; i < R0 * R0; i += PYR_THREADS) {
                 const int r = i / R0, c = i % R0;
@@ -340,15 +383,25 @@ hipError_t launch_rgbx_to_u8(const ImageView &src, uint8_t *dst, uint32_t dst_pi
     return hipGetLastError();
 }
 
-hipError_t launch_gaussian_pyramid(const PyramidView &pyr, hipStream_t stream)
+namespace {
+
+// levels 1.. of the pyramid, up to four steps per launch; `rgbx` != nullptr: the first launch also makes level 0 from it
+hipError_t launch_pyramid_levels(const PyramidView &pyr, const ImageView *rgbx, hipStream_t stream)
 {
     uint32_t lvl = 0;
     while (lvl + 1 < pyr.levels) {
-        const uint32_t ns = (pyr.levels - 1 - lvl) < 4u ? (pyr.levels - 1 - lvl) : 4u;
+        uint32_t ns = (pyr.levels - 1 - lvl) < 4u ? (pyr.levels - 1 - lvl) : 4u;
         PyrFusedArgs a{};
         a.src = pyr.ptr[lvl]; a.src_pitch = pyr.pitch[lvl];
         a.sw = (int)pyr.width[lvl]; a.sh = (int)pyr.height[lvl];
         a.aligned = ((uintptr_t)a.src % 4u == 0) && (a.src_pitch % 4u == 0);
+        const bool from_rgbx = rgbx != nullptr && lvl == 0;
+        // The launch that reads the colour frame builds ONE level: a tile's source region is then 67 x 67 pixels for the
+        // 64 x 64 it owns, against 109 x 109 with four levels under it -- the luma of the halo is computed by every tile
+        // that needs it, and the frame is 4 bytes a pixel.  Measured on the 32-stream bench (frames/s): 1 level 32.6 k,
+        // 2 levels 32.0 k, 3 levels 31.3 k, 4 levels 31.1 k, colour convert as its own launch 31.4 k.
+        if (from_rgbx) ns = 1;
+        if (from_rgbx) { a.rgbx = rgbx->ptr; a.rgbx_pitch = rgbx->pitch; }
         for (uint32_t g = 0; g < ns; ++g) {
             a.dst[g] = const_cast<uint8_t *>(pyr.ptr[lvl + 1 + g]);
             a.dst_pitch[g] = pyr.pitch[lvl + 1 + g];
@@ -356,17 +409,42 @@ hipError_t launch_gaussian_pyramid(const PyramidView &pyr, hipStream_t stream)
             a.dh[g] = (int)pyr.height[lvl + 1 + g];
         }
         const int tw = a.dw[ns - 1], th = a.dh[ns - 1];
+#define VSA_PYR_LAUNCH(NS_, T_)                                                                                                       \
+    do {                                                                                                                              \
+        const dim3 grid((tw + (T_) - 1) / (T_), (th + (T_) - 1) / (T_));                                                              \
+        if (from_rgbx) hipLaunchKernelGGL((k_pyramid_fused<NS_, T_, true>), grid, dim3(PYR_THREADS), 0, stream, a);                   \
+        else hipLaunchKernelGGL((k_pyramid_fused<NS_, T_, false>), grid, dim3(PYR_THREADS), 0, stream, a);                            \
+    } while (0)
         switch (ns) {
-        case 1: hipLaunchKernelGGL((k_pyramid_fused<1, 32>), dim3((tw + 31) / 32, (th + 31) / 32), dim3(PYR_THREADS), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((k_pyramid_fused<2, 16>), dim3((tw + 15) / 16, (th + 15) / 16), dim3(PYR_THREADS), 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((k_pyramid_fused<3, 8>), dim3((tw + 7) / 8, (th + 7) / 8), dim3(PYR_THREADS), 0, stream, a); break;
-        default: hipLaunchKernelGGL((k_pyramid_fused<4, 4>), dim3((tw + 3) / 4, (th + 3) / 4), dim3(PYR_THREADS), 0, stream, a); break;
+        case 1: VSA_PYR_LAUNCH(1, 32); break;
+        case 2: VSA_PYR_LAUNCH(2, 16); break;
+        case 3: VSA_PYR_LAUNCH(3, 8); break;
+        default: VSA_PYR_LAUNCH(4, 4); break;
         }
+#undef VSA_PYR_LAUNCH
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         lvl += ns;
     }
     return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t launch_gaussian_pyramid(const PyramidView &pyr, hipStream_t stream) { return launch_pyramid_levels(pyr, nullptr, stream); }
+
+bool color_pyramid_fusable(const ImageView &rgbx, const PyramidView &pyr)
+{
+    if (pyr.levels < 2 || rgbx.width != pyr.width[0] || rgbx.height != pyr.height[0] || rgbx.width == 0 || rgbx.height == 0) return false;
+    const uint32_t padded = (rgbx.width + 3u) & ~3u;      // the loads take whole groups of 4 pixels
+    return ((uintptr_t)rgbx.ptr % 16u == 0) && (rgbx.pitch % 16u == 0) && (rgbx.pitch >= 4u * padded) &&
+           ((uintptr_t)pyr.ptr[0] % 4u == 0) && (pyr.pitch[0] % 4u == 0) && (pyr.pitch[0] >= padded);
+}
+
+hipError_t launch_color_pyramid(const ImageView &rgbx, const PyramidView &pyr, hipStream_t stream)
+{
+    if (!color_pyramid_fusable(rgbx, pyr)) return hipErrorInvalidValue;
+    return launch_pyramid_levels(pyr, &rgbx, stream);
 }
 
 }  // namespace vsa

@@ -57,6 +57,12 @@ hipError_t launch_rgbx_to_u8(const ImageView &src, uint8_t *dst, uint32_t dst_pi
 // w = [1 4 6 4 1]; up to four steps fused per launch
 hipError_t launch_gaussian_pyramid(const PyramidView &pyr, hipStream_t stream);
 
+// RGBX -> U8 into level 0 AND levels 1..n-1 in the pyramid's first launch (one launch less than launch_rgbx_to_u8 +
+// launch_gaussian_pyramid, identical bytes).  Needs >= 2 levels, a 16-byte aligned frame whose rows are readable up to
+// the next multiple of 4 pixels, and a 4-byte aligned level 0: color_pyramid_fusable() says whether that holds.
+bool color_pyramid_fusable(const ImageView &rgbx, const PyramidView &pyr);
+hipError_t launch_color_pyramid(const ImageView &rgbx, const PyramidView &pyr, hipStream_t stream);
+
 // output(x,y) = input(X/Z, Y/Z) with (X,Y,Z) = m (x,y,1), m row-major; U8 (channels 1) or RGBX (channels 4, 4-byte
 // aligned); bilinear or nearest neighbour; samples outside the input take `border`
 struct WarpPerspectiveParams {

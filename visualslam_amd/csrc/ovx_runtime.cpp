@@ -166,6 +166,8 @@ struct _vx_node : _vx_reference {
     vx_perf_t perf{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    bool fused_away = false;          // K_COLOR_CONVERT: its work is done by the GaussianPyramid node it feeds (set by vxVerifyGraph)
+    _vx_node *fused_cvt = nullptr;    // K_GAUSSIAN_PYRAMID: the ColorConvert node whose RGBX input this node converts itself
     bool perf_enabled = false;        // vxDirective on this node alone (extension: narrower than the context-wide switch)
     void *scratch = nullptr;
     size_t scratch_size = 0;
@@ -571,6 +573,23 @@ vx_status do_gaussian_pyramid(_vx_image *in, _vx_pyramid *pyr, hipStream_t strea
     return hip_status(launch_gaussian_pyramid(v, stream));
 }
 
+// ColorConvert(RGBX -> level 0) + GaussianPyramid(level 0 -> pyramid) as one launch when the buffers allow it, as two
+// otherwise; the bytes are the same either way
+vx_status do_color_pyramid(_vx_image *rgbx, _vx_image *gray, _vx_pyramid *pyr, hipStream_t stream)
+{
+    if (!rgbx || !gray || !pyr) return VX_ERROR_INVALID_PARAMETERS;
+    if (rgbx->format == VX_DF_IMAGE_RGBX && rgbx->width == gray->width && rgbx->height == gray->height && gray->format == VX_DF_IMAGE_U8 &&
+        gray->width == pyr->width && gray->height == pyr->height && !pyr->levels.empty() && pyr->levels[0] == gray) {
+        PyramidView v{};
+        vx_status s = ensure_image(rgbx);
+        if (s == VX_SUCCESS) s = pyramid_view(pyr, &v);
+        if (s != VX_SUCCESS) return s;
+        if (color_pyramid_fusable(view_of(rgbx), v)) return hip_status(launch_color_pyramid(view_of(rgbx), v, stream));
+    }
+    vx_status s = do_color_convert(rgbx, gray, stream);
+    return s == VX_SUCCESS ? do_gaussian_pyramid(gray, pyr, stream) : s;
+}
+
 bool item_kind(vx_enum t, ItemKind *k)
 {
     if (t == NVX_TYPE_POINT2F) { *k = kPoint2f; return true; }
@@ -795,10 +814,14 @@ vx_status run_node(_vx_node *n, hipStream_t stream)
         return n->kernel->func(n, n->params.data(), (vx_uint32)n->params.size());
     }
     case K_COLOR_CONVERT:
+        if (n->fused_away) return VX_SUCCESS;       // the GaussianPyramid node it feeds converts the frame itself
         return do_color_convert(param<_vx_image>(n, 0, VX_TYPE_IMAGE), param<_vx_image>(n, 1, VX_TYPE_IMAGE), stream);
     case K_COPY_IMAGE:
         return do_copy_image(param<_vx_image>(n, 0, VX_TYPE_IMAGE), param<_vx_image>(n, 1, VX_TYPE_IMAGE), stream);
     case K_GAUSSIAN_PYRAMID:
+        if (n->fused_cvt)       // the ColorConvert node's CURRENT input: applications rebind it every frame
+            return do_color_pyramid(param<_vx_image>(n->fused_cvt, 0, VX_TYPE_IMAGE), param<_vx_image>(n, 0, VX_TYPE_IMAGE),
+                                    param<_vx_pyramid>(n, 1, VX_TYPE_PYRAMID), stream);
         return do_gaussian_pyramid(param<_vx_image>(n, 0, VX_TYPE_IMAGE), param<_vx_pyramid>(n, 1, VX_TYPE_PYRAMID), stream);
     case K_PYRLK:
         return do_pyrlk(param<_vx_pyramid>(n, 0, VX_TYPE_PYRAMID), param<_vx_pyramid>(n, 1, VX_TYPE_PYRAMID),
@@ -982,6 +1005,38 @@ vx_status verify_graph(_vx_graph *g)
         done[pick] = true;
         g->order.push_back(g->nodes[pick]);
         for (size_t s : succ[pick]) --indeg[s];
+    }
+    // Node fusion (what the callers' "-O3" verify option asks for, feature_tracker.cpp:435-436): ColorConvert writing level 0
+    // of a pyramid that a GaussianPyramid node then builds from that same level -- the tracker graphs' first two nodes
+    // (feature_tracker.cpp:360-362,386,393) -- run as ONE launch that reads the colour frame.  Legal when nothing reads
+    // the grey image between the two nodes; the ColorConvert node then does nothing when executed.
+    {
+        for (_vx_node *nd : g->nodes) { nd->fused_away = false; nd->fused_cvt = nullptr; }
+        std::vector<size_t> pos(n, 0);
+        for (size_t k = 0; k < n; ++k)
+            for (size_t i = 0; i < n; ++i)
+                if (g->nodes[i] == g->order[k]) pos[i] = k;
+        for (size_t gi = 0; gi < n && getenv("VISUALSLAM_AMD_NO_FUSION") == nullptr; ++gi) {
+            _vx_node *gp = g->nodes[gi];
+            if (gp->kind != K_GAUSSIAN_PYRAMID) continue;
+            auto *gray = param<_vx_image>(gp, 0, VX_TYPE_IMAGE);
+            auto *pyr = param<_vx_pyramid>(gp, 1, VX_TYPE_PYRAMID);
+            if (!gray || !pyr || pyr->levels.size() < 2 || pyr->levels[0] != gray || gray->parent) continue;
+            for (size_t ci = 0; ci < n; ++ci) {
+                _vx_node *cv = g->nodes[ci];
+                if (cv->kind != K_COLOR_CONVERT || param<_vx_image>(cv, 1, VX_TYPE_IMAGE) != gray || pos[ci] > pos[gi]) continue;
+                auto *frame = param<_vx_image>(cv, 0, VX_TYPE_IMAGE);
+                if (!frame || frame->format != VX_DF_IMAGE_RGBX) continue;
+                bool ok = true;      // every other reader of the grey image runs after the pyramid node
+                for (size_t b = 0; b < n && ok; ++b) {
+                    if (b == ci || b == gi) continue;
+                    std::vector<const void *> only_gray{ gray };
+                    if (intersects(rd[b], only_gray) && pos[b] < pos[gi]) ok = false;
+                }
+                if (ok) { cv->fused_away = true; gp->fused_cvt = cv; }
+                break;
+            }
+        }
     }
     // virtual images created with width = height = 0 take their size from the node that writes them
     for (_vx_node *nd : g->order) {

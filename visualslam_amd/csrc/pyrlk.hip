@@ -192,8 +192,10 @@ __device__ __forceinline__ bool tile_inside(int x0, int n, int nd, int w, uint32
 }
 
 // NSEG: max pixels per lane, WMAX: largest window of this instantiation (fixes LDS strides and slot
-// counts), ALIGNED: every level's base and pitch are multiples of 4
-template <int NSEG, int WMAX, bool ALIGNED>
+// counts), ALIGNED: every level's base and pitch are multiples of 4, FULL: every active lane's segment has exactly
+// NSEG pixels (the window splits evenly, e.g. 21 = 3 x 7) -- idle lanes then read a zeroed strip of LDS instead of
+// shadowing lane 0, and no lane needs the per-pixel "past my segment" selects
+template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
 __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 {
     constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;   // dwords per tile row
@@ -205,7 +207,9 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     constexpr int TBASE = PFLOATS + 64;                                                    // it follows the template tile and its slack; the
                                                                                            // search tile, committed after the pass, may overlap it
     constexpr int TEND = TBASE + (WMAX + 3) * TS;
-    constexpr int LDS_FLOATS = (JFLOATS + 64 > TEND) ? JFLOATS + 64 : TEND;
+    constexpr int TILE_FLOATS = (JFLOATS + 64 > TEND) ? JFLOATS + 64 : TEND;
+    constexpr int ZSTRIP = 3 * TS + PS + 32;                                               // FULL: a strip that stays zero, what idle lanes read
+    constexpr int LDS_FLOATS = TILE_FLOATS + (FULL ? ZSTRIP : 0);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
@@ -257,8 +261,14 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     int row = lane / a.segs;
     int x0 = (lane - row * a.segs) * a.seglen;
     int cnt = min(a.seglen, win - x0);
-    if (lane >= a.lanes || cnt < 0) { row = 0; x0 = 0; cnt = 0; }
-    const int lbaseP = row * PS + x0, lbaseJ = row * JS + x0, lbaseT = row * TS + x0;
+    const bool idle = lane >= a.lanes || cnt < 0;
+    if (idle) { row = 0; x0 = 0; cnt = 0; }
+    // FULL: an idle lane resamples and differentiates zeros (its template reads and its T row live in the zero strip),
+    // so its I, Ix, Iy are exact zeros without any select; its search-tile reads stay on real pixels (finite x 0)
+    const int lbaseP = (FULL && idle) ? TILE_FLOATS - PS : row * PS + x0;                       // reads start at TILE_FLOATS + (p_x0 & 3)
+    const int lbaseJ = row * JS + x0;
+    const int lbaseT = (FULL && idle) ? TILE_FLOATS + PS + NSEG + 8 - TBASE : row * TS + x0;    // T rows behind the strip's template part
+    static_assert(PS + NSEG + 8 + 2 * TS + NSEG + 2 <= ZSTRIP, "zero strip holds an idle lane's template and T accesses");
 
     // LDS only ever holds converted pixels, resampled template values or the zeros written here (the slack a lane may
     // over-read past its segment at the end of either tile region, T entries nobody computes), so idle pixels
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
                     const int k = j - 2;
                     float ix = sm - sm_pp;
                     float iy = fmaf(0.3125f, df_p, 0.09375f * (df_pp + df));
-                    if (k >= cnt) { ix = 0.0f; iy = 0.0f; }   // selects, not a branch
+                    if (!FULL && k >= cnt) { ix = 0.0f; iy = 0.0f; }   // selects, not a branch
                     Iw[k] = tc[k + 1];
                     Ix[k] = ix;
                     Iy[k] = iy;
@@ -401,7 +411,11 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             if (!(cx > -fw && cy > -fw && cx < flw + fw && cy < flh + fw)) { ok = false; break; }
             const float jfx = floorf(cx), jfy = floorf(cy);
             const float bx = cx - jfx, by = cy - jfy;
-            const int jx = __builtin_amdgcn_readfirstlane((int)jfx) - half, jy = __builtin_amdgcn_readfirstlane((int)jfy) - half;
+            // convert in the vector ALU, then ONE move to a scalar register per coordinate (left alone the compiler moves
+            // the float over first and converts it there, a second v_readfirstlane each)
+            int jxi = (int)jfx, jyi = (int)jfy;
+            asm volatile("" : "+v"(jxi), "+v"(jyi));
+            const int jx = __builtin_amdgcn_readfirstlane(jxi) - half, jy = __builtin_amdgcn_readfirstlane(jyi) - half;
             int ox = jx - jx0, oy = jy - jy0;
             if (ox < 0 || oy < 0 || ox > 2 * LK_MARGIN || oy > 2 * LK_MARGIN) {
                 // walked out of the staged tile: restage around the current position (rare)
@@ -506,13 +520,19 @@ hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipSt
 {
     constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;
     constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
-    constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * 4 * (NDP | 1), JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * 4 * (NDJ | 1);
+    constexpr int PS = 4 * (NDP | 1);
+    constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * PS, JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * 4 * (NDJ | 1);
     constexpr int TS = (WMAX + NSEG + 2) | 1;
     constexpr int TEND = PFLOATS + 64 + (WMAX + 3) * TS;   // template tile + zeroed slack + T tile; the search tile overlaps T
-    constexpr size_t lds = ((JFLOATS + 64 > TEND) ? JFLOATS + 64 : TEND) * sizeof(float);
+    constexpr int TILE_FLOATS = (JFLOATS + 64 > TEND) ? JFLOATS + 64 : TEND;
+    // every active lane has a whole segment of NSEG pixels: the specialisation without per-pixel selects (+ a zero strip in LDS)
+    const bool full = a.seglen == NSEG && a.segs * a.seglen == a.win;
+    const size_t lds = (size_t)(TILE_FLOATS + (full ? 3 * TS + PS + 32 : 0)) * sizeof(float);
     const dim3 grid(capacity), block(64);
-    if (aligned) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false>), grid, block, lds, stream, a);
+    if (aligned && full) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true, true>), grid, block, lds, stream, a);
+    else if (aligned) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true, false>), grid, block, lds, stream, a);
+    else if (full) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false, false>), grid, block, lds, stream, a);
     return hipGetLastError();
 }
 
