@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <climits>
 
 #include "kernels.hpp"
 
@@ -128,46 +129,39 @@ __device__ __forceinline__ float wave_sum(float v)
 // 32 floats put every other row on the same banks: 43% of PyrLK's LDS cycles were bank conflicts).  Slots past
 // the last tile row fetch (clamped) rows below it; they only fill LDS that nobody interprets.
 template <int NL>
-struct TileSlots {
-    int row[NL], col4[NL];   // this lane's slots: tile row and byte offset 4*dword inside the row (level-invariant)
-    int lds4[NL];            // float4 index of the slot in LDS
-};
-template <int NL>
 struct TileRegs {
     uint32_t v[NL];
 };
 
-template <int NL, int ND, int LS4>
-__device__ __forceinline__ void tile_slots(TileSlots<NL> &s, int lane)
-{
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int idx = lane + 64 * i;
-        s.row[i] = idx / ND;
-        s.col4[i] = 4 * (idx - s.row[i] * ND);
-        s.lds4[i] = s.row[i] * LS4 + (idx - s.row[i] * ND);
-    }
-}
+// Which (row, dword) slot i of a lane is never changes, but holding the three indices of all eight slots in registers
+// costs 24 VGPRs that are live across the iteration loop.  They are recomputed where a tile is issued or committed
+// (a division by a constant and two multiply-adds per slot, outside the iteration loop) from an opaque copy of the lane
+// number, so that the compiler cannot hoist them back out of the level loop: the registers go to the iteration loop's
+// cache of search rows instead, and the kernel stays at 4 waves per SIMD with room for other kernels' waves.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // fast: the tile's dwords lie inside the row allocation and inside the image columns, and the level is
 // 4-byte aligned -> one dword load per slot.  Otherwise four clamped byte loads (replicate border).
-template <int NL>
-__device__ __forceinline__ void tile_issue(TileRegs<NL> &t, const TileSlots<NL> &s, const uint8_t *img, uint32_t pitch,
+template <int NL, int ND>
+__device__ __forceinline__ void tile_issue(TileRegs<NL> &t, int lane, const uint8_t *img, uint32_t pitch,
                                            int w, int h, int x0, int y0, bool fast)
 {
     const int xa = x0 & ~3;
+    lane = opaque(lane);
     if (fast) {   // wave-uniform
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int gy = min(max(y0 + s.row[i], 0), h - 1);
-            t.v[i] = *reinterpret_cast<const uint32_t *>(img + ((uint32_t)gy * pitch + (uint32_t)(xa + s.col4[i])));
+            const int idx = lane + 64 * i, row = idx / ND, col4 = 4 * (idx - row * ND);
+            const int gy = min(max(y0 + row, 0), h - 1);
+            t.v[i] = *reinterpret_cast<const uint32_t *>(img + ((uint32_t)gy * pitch + (uint32_t)(xa + col4)));
         }
     } else {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int gy = min(max(y0 + s.row[i], 0), h - 1);
+            const int idx = lane + 64 * i, row = idx / ND, col4 = 4 * (idx - row * ND);
+            const int gy = min(max(y0 + row, 0), h - 1);
             const uint8_t *rowp = img + (uint32_t)gy * pitch;
-            const int X = xa + s.col4[i];
+            const int X = xa + col4;
             const uint32_t b0 = rowp[min(max(X, 0), w - 1)], b1 = rowp[min(max(X + 1, 0), w - 1)];
             const uint32_t b2 = rowp[min(max(X + 2, 0), w - 1)], b3 = rowp[min(max(X + 3, 0), w - 1)];
             t.v[i] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
@@ -175,14 +169,16 @@ __device__ __forceinline__ void tile_issue(TileRegs<NL> &t, const TileSlots<NL> 
     }
 }
 
-template <int NL>
-__device__ __forceinline__ void tile_commit(const TileRegs<NL> &t, const TileSlots<NL> &s, float *dst)
+template <int NL, int ND, int LS4>
+__device__ __forceinline__ void tile_commit(const TileRegs<NL> &t, int lane, float *dst)
 {
     float4 *d4 = reinterpret_cast<float4 *>(dst);
+    lane = opaque(lane);
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
+        const int idx = lane + 64 * i, row = idx / ND;
         const uint32_t v = t.v[i];
-        d4[s.lds4[i]] = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+        d4[row * LS4 + (idx - row * ND)] = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
     }
 }
 
@@ -196,7 +192,7 @@ __device__ __forceinline__ bool tile_inside(int x0, int n, int nd, int w, uint32
 // NSEG pixels (the window splits evenly, e.g. 21 = 3 x 7) -- idle lanes then read a zeroed strip of LDS instead of
 // shadowing lane 0, and no lane needs the per-pixel "past my segment" selects
 template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
-__global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
+__device__ __forceinline__ void pyrlk_wave(const LKArgs &a)
 {
     constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;   // dwords per tile row
     constexpr int PS4 = NDP | 1, JS4 = NDJ | 1;                                            // LDS row strides (float4), odd
@@ -275,11 +271,6 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
     // multiply finite values by exact zeros
     for (int i = PFLOATS + lane; i < LDS_FLOATS; i += 64) smem[i] = 0.0f;
 
-    TileSlots<NLP> sp;
-    TileSlots<NLJ> sj;
-    tile_slots<NLP, NDP, PS4>(sp, lane);
-    tile_slots<NLJ, NDJ, JS4>(sj, lane);
-
     const int top = (int)a.prev.levels - 1;
     const float s_top = 1.0f / (float)(1u << top);
     float gx = (ex - px) * s_top, gy = (ey - py) * s_top;
@@ -297,7 +288,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         p_x0 = (int)floorf(px * s_top) - half - 1;
         const int p_y0 = (int)floorf(py * s_top) - half - 1;
         const int tw = (int)a.prev.width[top];
-        tile_issue(tp, sp, a.prev.ptr[top], a.prev.pitch[top], tw, (int)a.prev.height[top], p_x0, p_y0,
+        tile_issue<NLP, NDP>(tp, lane, a.prev.ptr[top], a.prev.pitch[top], tw, (int)a.prev.height[top], p_x0, p_y0,
                    ALIGNED && tile_inside(p_x0, PW, NDP, tw, a.prev.pitch[top]));
     }
 
@@ -313,10 +304,10 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         // search tile around the prediction: its loads fly while the template is resampled
         int jx0 = (int)floorf(ux + gx) - half - LK_MARGIN;
         int jy0 = (int)floorf(uy + gy) - half - LK_MARGIN;
-        tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
+        tile_issue<NLJ, NDJ>(tj, lane, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
 
         __syncthreads();   // previous level's search tile is dead
-        tile_commit(tp, sp, P);
+        tile_commit<NLP, NDP, PS4>(tp, lane, P);
         __syncthreads();
         LK_PHASE(0);
 
@@ -385,7 +376,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             p_x0 = (int)floorf(px * sn) - half - 1;
             const int p_y0 = (int)floorf(py * sn) - half - 1;
             const int nw = (int)a.prev.width[L - 1];
-            tile_issue(tp, sp, a.prev.ptr[L - 1], a.prev.pitch[L - 1], nw, (int)a.prev.height[L - 1], p_x0, p_y0,
+            tile_issue<NLP, NDP>(tp, lane, a.prev.ptr[L - 1], a.prev.pitch[L - 1], nw, (int)a.prev.height[L - 1], p_x0, p_y0,
                        ALIGNED && tile_inside(p_x0, PW, NDP, nw, a.prev.pitch[L - 1]));
         }
 
@@ -402,10 +393,12 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
         const float flw = (float)lw, flh = (float)lh;
 
         __syncthreads();   // every lane is done with P
-        tile_commit(tj, sj, J);
+        tile_commit<NLJ, NDJ, JS4>(tj, lane, J);
         __syncthreads();
         LK_PHASE(2);
 
+        float ja[NSEG + 1], jb[NSEG + 1];                     // search rows jy + row and jy + row + 1 at columns jx + x0 ..
+        int cached_jx = INT_MIN, cached_jy = INT_MIN;         // ... for this integer position (none yet at this level)
         for (uint32_t it = 0; it < a.max_it; ++it) {
             const float cx = (ux + gx) + vx, cy = (uy + gy) + vy;
             if (!(cx > -fw && cy > -fw && cx < flw + fw && cy < flh + fw)) { ok = false; break; }
@@ -420,21 +413,30 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             if (ox < 0 || oy < 0 || ox > 2 * LK_MARGIN || oy > 2 * LK_MARGIN) {
                 // walked out of the staged tile: restage around the current position (rare)
                 jx0 = jx - LK_MARGIN; jy0 = jy - LK_MARGIN; ox = LK_MARGIN; oy = LK_MARGIN;
-                tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
+                tile_issue<NLJ, NDJ>(tj, lane, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
                 __syncthreads();
-                tile_commit(tj, sj, J);
+                tile_commit<NLJ, NDJ, JS4>(tj, lane, J);
                 __syncthreads();
             }
 #ifdef VSA_LK_STAMPS
             ++st_iters;
 #endif
+            // The two search-tile rows a lane samples depend only on the INTEGER part of the position.  After a level's first
+            // iteration the update is usually a fraction of a pixel, so the rows are kept in registers and re-read only when
+            // the integer position moves: the iteration loop is bound by the LDS pipe (16 dword reads per lane with 2-way
+            // bank conflicts; profiles/r02_kernel_experiments.txt), and most iterations now read nothing.
+            if (jx != cached_jx || jy != cached_jy) {   // wave-uniform
+                const float *jt = J + lbaseJ + (oy * JS + (jx0 & 3) + ox);
+#pragma unroll
+                for (int k = 0; k < NSEG + 1; ++k) { ja[k] = jt[k]; jb[k] = jt[JS + k]; }
+                cached_jx = jx; cached_jy = jy;
+            }
             float b1 = 0.0f, b2 = 0.0f;
             {
-                const float *jt = J + lbaseJ + (oy * JS + (jx0 & 3) + ox);
-                float cp = fmaf(by, jt[JS] - jt[0], jt[0]);
+                float cp = fmaf(by, jb[0] - ja[0], ja[0]);
 #pragma unroll
                 for (int k = 0; k < NSEG; ++k) {   // pixels past cnt have Ix = Iy = 0 and add exact zeros
-                    const float cc = fmaf(by, jt[JS + k + 1] - jt[k + 1], jt[k + 1]);
+                    const float cc = fmaf(by, jb[k + 1] - ja[k + 1], ja[k + 1]);
                     const float jv = fmaf(bx, cc - cp, cp);
                     const float d = Iw[k] - jv;
                     b1 = fmaf(d, Ix[k], b1);
@@ -461,9 +463,9 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
                 int ox = jx - jx0, oy = jy - jy0;
                 if (ox < 0 || oy < 0 || ox > 2 * LK_MARGIN || oy > 2 * LK_MARGIN) {
                     jx0 = jx - LK_MARGIN; jy0 = jy - LK_MARGIN; ox = LK_MARGIN; oy = LK_MARGIN;
-                    tile_issue(tj, sj, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
+                    tile_issue<NLJ, NDJ>(tj, lane, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
                     __syncthreads();
-                    tile_commit(tj, sj, J);
+                    tile_commit<NLJ, NDJ, JS4>(tj, lane, J);
                     __syncthreads();
                 }
                 const float *jt = J + lbaseJ + (oy * JS + (jx0 & 3) + ox);
@@ -476,7 +478,9 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
                     e = e + (k < cnt ? fabsf(Iw[k] - jv) : 0.0f);
                     cp = cc;
                 }
-                err = wave_sum(e) * (1.0f / (float)(win * win));
+                int area = win * win;
+                asm volatile("" : "+s"(area));   // keeps the reciprocal here: hoisted to the kernel's head it holds a register throughout
+                err = wave_sum(e) * (1.0f / (float)area);
             }
         }
     }
@@ -495,8 +499,13 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
             const KeypointF *src = reinterpret_cast<const KeypointF *>(a.prev_pts) + pi;
             KeypointF *dst = reinterpret_cast<KeypointF *>(a.out) + pi;
             const float strength = src->strength, scale = src->scale, orientation = src->orientation;
-            dst->x = ok ? rx : ex;
-            dst->y = ok ? ry : ey;
+            // a lost item keeps its estimate: read again here (through a pointer the compiler cannot match with the first
+            // read) rather than held in two registers from the kernel's head to its last instructions
+            const KeypointF *est = reinterpret_cast<const KeypointF *>(a.estimates);
+            asm volatile("" : "+s"(est));
+            const float lost_x = est[pi].x, lost_y = est[pi].y;
+            dst->x = ok ? rx : lost_x;
+            dst->y = ok ? ry : lost_y;
             dst->strength = strength;
             dst->scale = scale;
             dst->orientation = orientation;
@@ -515,6 +524,21 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 #endif
 }
 
+template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
+__global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
+{
+    pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a);
+}
+// The 21 x 21 bucket (the feature tracker's default window) with at most 104 registers: four of its waves then leave 96 of a
+// SIMD's 512 registers to other camera streams' detector (92) and merge (48) waves, which otherwise wait for PyrLK waves to
+// drain (-9 % on the 32-stream bench at 109 registers).  On gfx950 the attribute counts the unified VGPR + AGPR file in
+// halves: 52 caps the kernel at 104.
+template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(52))) void k_pyrlk_104(LKArgs a)
+{
+    pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a);
+}
+
 template <int NSEG, int WMAX>
 hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipStream_t stream)
 {
@@ -529,10 +553,17 @@ hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipSt
     const bool full = a.seglen == NSEG && a.segs * a.seglen == a.win;
     const size_t lds = (size_t)(TILE_FLOATS + (full ? 3 * TS + PS + 32 : 0)) * sizeof(float);
     const dim3 grid(capacity), block(64);
-    if (aligned && full) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true, true>), grid, block, lds, stream, a);
-    else if (aligned) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true, false>), grid, block, lds, stream, a);
-    else if (full) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false, false>), grid, block, lds, stream, a);
+    if constexpr (NSEG == 7) {
+        if (aligned && full) hipLaunchKernelGGL((k_pyrlk_104<NSEG, WMAX, true, true>), grid, block, lds, stream, a);
+        else if (aligned) hipLaunchKernelGGL((k_pyrlk_104<NSEG, WMAX, true, false>), grid, block, lds, stream, a);
+        else if (full) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false, false>), grid, block, lds, stream, a);
+    } else {
+        if (aligned && full) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true, true>), grid, block, lds, stream, a);
+        else if (aligned) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, true, false>), grid, block, lds, stream, a);
+        else if (full) hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false, true>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((k_pyrlk<NSEG, WMAX, false, false>), grid, block, lds, stream, a);
+    }
     return hipGetLastError();
 }
 
