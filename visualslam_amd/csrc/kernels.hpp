@@ -99,6 +99,10 @@ struct CornerTrackParams {
 };
 
 size_t corner_track_scratch_bytes(uint32_t width, uint32_t height, uint32_t cell_size);
+// cell pass (one key per detector cell into p.scratch; reads the image and the mask only) + merge pass (tracked points and
+// keys -> output array); launch_corner_track = both, one after the other
+hipError_t launch_corner_cells(const CornerTrackParams &p, hipStream_t stream);
+hipError_t launch_corner_merge(const CornerTrackParams &p, hipStream_t stream);
 hipError_t launch_corner_track(const CornerTrackParams &p, hipStream_t stream);
 
 struct PyrLKParams {
@@ -121,6 +125,13 @@ struct PyrLKParams {
 // one kernel (pyrlk.hip): aligned dword staging when every level is 4-byte aligned, per-byte clamped loads
 // otherwise; both produce identical results
 hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream);
+
+// PyrLK and the Harris-track CELL pass of the detector node that follows it in ONE launch (one wave per feature, then one
+// wave per rectangle of cells, filling the compute units the last PyrLK waves leave idle): the cell pass reads only the
+// image, so only launch_corner_merge(ct) has to follow.  Results are those of launch_pyrlk + launch_corner_cells.
+// pyrlk_cells_fusable(): a Harris detector and 4-byte aligned pyramids.
+bool pyrlk_cells_fusable(const PyrLKParams &lk, const CornerTrackParams &ct);
+hipError_t launch_pyrlk_with_cells(const PyrLKParams &lk, const CornerTrackParams &ct, hipStream_t stream);
 
 // nvxFindHomography (RANSAC) on POINT2F correspondences (homography.hip; semantics: oracle/vxoracle_homography.c)
 struct HomographyParams {

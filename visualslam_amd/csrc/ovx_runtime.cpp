@@ -168,6 +168,8 @@ struct _vx_node : _vx_reference {
     bool timed = false;
     bool fused_away = false;          // K_COLOR_CONVERT: its work is done by the GaussianPyramid node it feeds (set by vxVerifyGraph)
     _vx_node *fused_cvt = nullptr;    // K_GAUSSIAN_PYRAMID: the ColorConvert node whose RGBX input this node converts itself
+    _vx_node *fused_cells = nullptr;  // K_PYRLK: the HarrisTrack node whose cell pass may run inside this node's launch (vxVerifyGraph)
+    bool cells_done = false;          // K_HARRIS_TRACK: this execution's cell pass has run in the PyrLK node's launch; merge only
     bool perf_enabled = false;        // vxDirective on this node alone (extension: narrower than the context-wide switch)
     void *scratch = nullptr;
     size_t scratch_size = 0;
@@ -597,15 +599,16 @@ bool item_kind(vx_enum t, ItemKind *k)
     return false;
 }
 
-vx_status do_pyrlk(_vx_pyramid *oldp, _vx_pyramid *newp, _vx_array *oldpts, _vx_array *est, _vx_array *out,
-                   vx_enum term, _vx_scalar *eps, _vx_scalar *iters, _vx_scalar *use_est, vx_size win, hipStream_t stream)
+vx_status prep_pyrlk(_vx_pyramid *oldp, _vx_pyramid *newp, _vx_array *oldpts, _vx_array *est, _vx_array *out,
+                     vx_enum term, _vx_scalar *eps, _vx_scalar *iters, _vx_scalar *use_est, vx_size win, PyrLKParams *pp)
 {
     if (!oldp || !newp || !oldpts || !out || !eps || !iters) return VX_ERROR_INVALID_PARAMETERS;
     if (win < (vx_size)kLkMinWin || win > (vx_size)kLkMaxWin) return VX_ERROR_INVALID_VALUE;
     if (term != VX_TERM_CRITERIA_ITERATIONS && term != VX_TERM_CRITERIA_EPSILON && term != VX_TERM_CRITERIA_BOTH)
         return VX_ERROR_INVALID_VALUE;
     if (eps->data_type != VX_TYPE_FLOAT32 || iters->data_type != VX_TYPE_UINT32) return VX_ERROR_INVALID_TYPE;
-    PyrLKParams p{};
+    PyrLKParams &p = *pp;
+    p = PyrLKParams{};
     if (oldpts->item_type != out->item_type || !item_kind(oldpts->item_type, &p.item)) return VX_ERROR_NOT_SUPPORTED;
     if (oldpts == out) return VX_ERROR_INVALID_PARAMETERS;
     const bool with_est = use_est && use_est->v.b != vx_false_e && est;
@@ -630,18 +633,27 @@ vx_status do_pyrlk(_vx_pyramid *oldp, _vx_pyramid *newp, _vx_array *oldpts, _vx_
     p.max_iterations = term == VX_TERM_CRITERIA_EPSILON ? 100u : iters->v.u32;
     p.epsilon = eps->v.f32;
     p.window = (uint32_t)win;
-    return hip_status(launch_pyrlk(p, stream));
+    return VX_SUCCESS;
 }
 
-vx_status do_corner_track(Detector det, _vx_image *in, _vx_array *out, _vx_image *mask, _vx_array *tracked,
-                          float k, float thr, uint32_t fast_n, uint32_t cell, size_t *dev_num_corners,
-                          uint64_t *num_corners_mirror, void *scratch, size_t scratch_size, hipStream_t stream)
+vx_status do_pyrlk(_vx_pyramid *oldp, _vx_pyramid *newp, _vx_array *oldpts, _vx_array *est, _vx_array *out,
+                   vx_enum term, _vx_scalar *eps, _vx_scalar *iters, _vx_scalar *use_est, vx_size win, hipStream_t stream)
+{
+    PyrLKParams p{};
+    const vx_status s = prep_pyrlk(oldp, newp, oldpts, est, out, term, eps, iters, use_est, win, &p);
+    return s != VX_SUCCESS ? s : hip_status(launch_pyrlk(p, stream));
+}
+
+vx_status prep_corner_track(Detector det, _vx_image *in, _vx_array *out, _vx_image *mask, _vx_array *tracked,
+                            float k, float thr, uint32_t fast_n, uint32_t cell, size_t *dev_num_corners,
+                            uint64_t *num_corners_mirror, void *scratch, size_t scratch_size, CornerTrackParams *pp)
 {
     if (!in || !out) return VX_ERROR_INVALID_PARAMETERS;
     if (in->format != VX_DF_IMAGE_U8) return VX_ERROR_INVALID_FORMAT;
     if (cell == 0) return VX_ERROR_INVALID_VALUE;
     if (det == kFast && (fast_n < 9 || fast_n > 12 || thr >= 255.0f)) return VX_ERROR_INVALID_VALUE;
-    CornerTrackParams p{};
+    CornerTrackParams &p = *pp;
+    p = CornerTrackParams{};
     if (!item_kind(out->item_type, &p.item)) return VX_ERROR_NOT_SUPPORTED;
     vx_status s = ensure_image(in);
     if (s == VX_SUCCESS) s = ensure_array(out);
@@ -670,7 +682,19 @@ vx_status do_corner_track(Detector det, _vx_image *in, _vx_array *out, _vx_image
     p.fast_n = fast_n;
     p.cell_size = cell;
     p.scratch = scratch;
-    return hip_status(launch_corner_track(p, stream));
+    return VX_SUCCESS;
+}
+
+// merge_only: the cell pass of this execution has already run (inside the PyrLK node's launch)
+vx_status do_corner_track(Detector det, _vx_image *in, _vx_array *out, _vx_image *mask, _vx_array *tracked,
+                          float k, float thr, uint32_t fast_n, uint32_t cell, size_t *dev_num_corners,
+                          uint64_t *num_corners_mirror, void *scratch, size_t scratch_size, hipStream_t stream, bool merge_only = false)
+{
+    CornerTrackParams p{};
+    const vx_status s = prep_corner_track(det, in, out, mask, tracked, k, thr, fast_n, cell, dev_num_corners, num_corners_mirror,
+                                          scratch, scratch_size, &p);
+    if (s != VX_SUCCESS) return s;
+    return hip_status(merge_only ? launch_corner_merge(p, stream) : launch_corner_track(p, stream));
 }
 
 vx_status do_find_homography(_vx_array *src, _vx_array *dst, _vx_matrix *mat, vx_enum method, float threshold,
@@ -823,22 +847,43 @@ vx_status run_node(_vx_node *n, hipStream_t stream)
             return do_color_pyramid(param<_vx_image>(n->fused_cvt, 0, VX_TYPE_IMAGE), param<_vx_image>(n, 0, VX_TYPE_IMAGE),
                                     param<_vx_pyramid>(n, 1, VX_TYPE_PYRAMID), stream);
         return do_gaussian_pyramid(param<_vx_image>(n, 0, VX_TYPE_IMAGE), param<_vx_pyramid>(n, 1, VX_TYPE_PYRAMID), stream);
-    case K_PYRLK:
-        return do_pyrlk(param<_vx_pyramid>(n, 0, VX_TYPE_PYRAMID), param<_vx_pyramid>(n, 1, VX_TYPE_PYRAMID),
-                        param<_vx_array>(n, 2, VX_TYPE_ARRAY), param<_vx_array>(n, 3, VX_TYPE_ARRAY),
-                        param<_vx_array>(n, 4, VX_TYPE_ARRAY), pyrlk_termination(n), param<_vx_scalar>(n, 6, VX_TYPE_SCALAR),
-                        param<_vx_scalar>(n, 7, VX_TYPE_SCALAR), param<_vx_scalar>(n, 8, VX_TYPE_SCALAR), pyrlk_window(n), stream);
+    case K_PYRLK: {
+        PyrLKParams lk{};
+        vx_status s = prep_pyrlk(param<_vx_pyramid>(n, 0, VX_TYPE_PYRAMID), param<_vx_pyramid>(n, 1, VX_TYPE_PYRAMID),
+                                 param<_vx_array>(n, 2, VX_TYPE_ARRAY), param<_vx_array>(n, 3, VX_TYPE_ARRAY),
+                                 param<_vx_array>(n, 4, VX_TYPE_ARRAY), pyrlk_termination(n), param<_vx_scalar>(n, 6, VX_TYPE_SCALAR),
+                                 param<_vx_scalar>(n, 7, VX_TYPE_SCALAR), param<_vx_scalar>(n, 8, VX_TYPE_SCALAR), pyrlk_window(n), &lk);
+        if (s != VX_SUCCESS) return s;
+        if (_vx_node *h = n->fused_cells) {
+            // the HarrisTrack node that merges this node's output: its cell pass (which reads the image only) rides in this
+            // launch, with that node's CURRENT parameters; whatever keeps it from doing so leaves the node to run in full
+            h->cells_done = false;
+            CornerTrackParams ct{};
+            if (node_scratch(h) == VX_SUCCESS &&
+                prep_corner_track(kHarris, param<_vx_image>(h, 0, VX_TYPE_IMAGE), param<_vx_array>(h, 1, VX_TYPE_ARRAY),
+                                  param<_vx_image>(h, 2, VX_TYPE_IMAGE), param<_vx_array>(h, 3, VX_TYPE_ARRAY), scalar_f32(h, 4),
+                                  scalar_f32(h, 5), 0u, scalar_u32(h, 6), nullptr, nullptr, h->scratch, h->scratch_size, &ct) == VX_SUCCESS &&
+                pyrlk_cells_fusable(lk, ct)) {
+                s = hip_status(launch_pyrlk_with_cells(lk, ct, stream));
+                h->cells_done = s == VX_SUCCESS;
+                return s;
+            }
+        }
+        return hip_status(launch_pyrlk(lk, stream));
+    }
     case K_HARRIS_TRACK:
     case K_FAST_TRACK: {
         vx_status s = node_scratch(n);
         if (s != VX_SUCCESS) return s;
         const bool harris = n->kind == K_HARRIS_TRACK;
+        const bool merge_only = n->cells_done;
+        n->cells_done = false;
         return do_corner_track(harris ? kHarris : kFast, param<_vx_image>(n, 0, VX_TYPE_IMAGE),
                                param<_vx_array>(n, 1, VX_TYPE_ARRAY), param<_vx_image>(n, 2, VX_TYPE_IMAGE),
                                param<_vx_array>(n, 3, VX_TYPE_ARRAY), harris ? scalar_f32(n, 4) : 0.0f,
                                harris ? scalar_f32(n, 5) : (float)scalar_u32(n, 5), harris ? 0u : scalar_u32(n, 4),
                                scalar_u32(n, 6), param<_vx_scalar>(n, 7, VX_TYPE_SCALAR) ? n->dev_num_corners : nullptr,
-                               n->num_corners_mirror, n->scratch, n->scratch_size, stream);
+                               n->num_corners_mirror, n->scratch, n->scratch_size, stream, merge_only);
     }
     }
     return VX_ERROR_NOT_IMPLEMENTED;
@@ -1011,7 +1056,7 @@ vx_status verify_graph(_vx_graph *g)
     // (feature_tracker.cpp:360-362,386,393) -- run as ONE launch that reads the colour frame.  Legal when nothing reads
     // the grey image between the two nodes; the ColorConvert node then does nothing when executed.
     {
-        for (_vx_node *nd : g->nodes) { nd->fused_away = false; nd->fused_cvt = nullptr; }
+        for (_vx_node *nd : g->nodes) { nd->fused_away = false; nd->fused_cvt = nullptr; nd->fused_cells = nullptr; nd->cells_done = false; }
         std::vector<size_t> pos(n, 0);
         for (size_t k = 0; k < n; ++k)
             for (size_t i = 0; i < n; ++i)
@@ -1034,6 +1079,28 @@ vx_status verify_graph(_vx_graph *g)
                     if (intersects(rd[b], only_gray) && pos[b] < pos[gi]) ok = false;
                 }
                 if (ok) { cv->fused_away = true; gp->fused_cvt = cv; }
+                break;
+            }
+        }
+        // A HarrisTrack node that merges a PyrLK node's output (feature_tracker.cpp:402-422): only its merge pass needs the
+        // tracked points; its cell pass reads the image and the mask, which are ready when PyrLK starts if no node from the
+        // PyrLK node up to the HarrisTrack node writes them.  The cell pass then runs inside the PyrLK launch, whose last
+        // waves otherwise leave compute units idle, and the frame has one launch less.
+        for (size_t hi = 0; hi < n && getenv("VISUALSLAM_AMD_NO_FUSION") == nullptr; ++hi) {
+            _vx_node *ht = g->nodes[hi];
+            if (ht->kind != K_HARRIS_TRACK) continue;
+            auto *tracked = param<_vx_array>(ht, 3, VX_TYPE_ARRAY);
+            if (!tracked) continue;
+            for (size_t li = 0; li < n; ++li) {
+                _vx_node *lk = g->nodes[li];
+                if (lk->kind != K_PYRLK || lk->fused_cells || param<_vx_array>(lk, 4, VX_TYPE_ARRAY) != tracked || pos[li] > pos[hi]) continue;
+                std::vector<const void *> inputs;
+                keys_of(ht->params[0], &inputs);
+                if (ht->params.size() > 2 && ht->params[2]) keys_of(ht->params[2], &inputs);
+                bool ok = true;
+                for (size_t b = 0; b < n && ok; ++b)
+                    if (pos[b] >= pos[li] && pos[b] < pos[hi] && intersects(wr[b], inputs)) ok = false;
+                if (ok) lk->fused_cells = ht;
                 break;
             }
         }

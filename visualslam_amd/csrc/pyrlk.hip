@@ -31,6 +31,7 @@
 #include <climits>
 
 #include "kernels.hpp"
+#include "harris_cells.hpp"
 
 namespace vsa {
 namespace {
@@ -192,7 +193,7 @@ __device__ __forceinline__ bool tile_inside(int x0, int n, int nd, int w, uint32
 // NSEG pixels (the window splits evenly, e.g. 21 = 3 x 7) -- idle lanes then read a zeroed strip of LDS instead of
 // shadowing lane 0, and no lane needs the per-pixel "past my segment" selects
 template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
-__device__ __forceinline__ void pyrlk_wave(const LKArgs &a)
+__device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, float *smem)
 {
     constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;   // dwords per tile row
     constexpr int PS4 = NDP | 1, JS4 = NDJ | 1;                                            // LDS row strides (float4), odd
@@ -207,7 +208,6 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a)
     constexpr int ZSTRIP = 3 * TS + PS + 32;                                               // FULL: a strip that stays zero, what idle lanes read
     constexpr int LDS_FLOATS = TILE_FLOATS + (FULL ? ZSTRIP : 0);
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x;
     const bool lane_bit0 = lane & 1, lane_bit1 = lane & 2;
 #ifdef VSA_LK_STAMPS
@@ -221,14 +221,14 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a)
 #define LK_PHASE(i) do { } while (0)
 #endif
     const uint32_t n = min(*a.prev_count, a.capacity);
-    if (blockIdx.x == 0 && lane == 0) {
+    if (bid == 0 && lane == 0) {
         *a.out_count = n;
         if (a.out_count_host) *a.out_count_host = n;
     }
-    if (blockIdx.x >= n) return;
+    if (bid >= n) return;
     // features arrive in detector-cell raster order: consecutive features are image neighbours, so give
     // each XCD a contiguous run of them (their tiles overlap in that XCD's L2)
-    const uint32_t pi = xcd_contiguous_item(blockIdx.x, n);
+    const uint32_t pi = xcd_contiguous_item(bid, n);
 
     float px, py, ex, ey;
     bool alive = true;
@@ -275,7 +275,13 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a)
     const float s_top = 1.0f / (float)(1u << top);
     float gx = (ex - px) * s_top, gy = (ey - py) * s_top;
     float vx = 0.0f, vy = 0.0f;
-    const float inv_area = 1.0f / (float)(2 * win * win);
+    // wave-uniform and needed once per level: held in a scalar register, not in one of the 104 vector registers
+    // (an explicit move: the compiler drops a readfirstlane builtin of a value it already knows to be uniform)
+    float inv_area;
+    {
+        const float v = 1.0f / (float)(2 * win * win);
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(inv_area) : "v"(v));
+    }
     const float fw = (float)win;
 
     float Iw[NSEG], Ix[NSEG], Iy[NSEG];
@@ -514,9 +520,9 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a)
         }
     }
 #ifdef VSA_LK_STAMPS
-    if (lane == 0 && blockIdx.x < 8192) {
+    if (lane == 0 && bid < 8192) {
         const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        uint64_t *o = g_lk_stamps + 8 * blockIdx.x;
+        uint64_t *o = g_lk_stamps + 8 * bid;
         o[0] = st_t0; o[1] = __builtin_readcyclecounter(); o[2] = ((uint64_t)xcc << 32) | hw;
         o[3] = ((wall_clock64() - st_w0) << 32) | st_iters;
         o[4] = st_ph[0]; o[5] = st_ph[1]; o[6] = st_ph[2]; o[7] = st_ph[3];
@@ -527,7 +533,8 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a)
 template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
 __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 {
-    pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a, blockIdx.x, smem);
 }
 // The 21 x 21 bucket (the feature tracker's default window) with at most 104 registers: four of its waves then leave 96 of a
 // SIMD's 512 registers to other camera streams' detector (92) and merge (48) waves, which otherwise wait for PyrLK waves to
@@ -536,11 +543,34 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(52))) void k_pyrlk_104(LKArgs a)
 {
-    pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a, blockIdx.x, smem);
+}
+
+// PyrLK + the Harris-track cell pass in one launch (launch_pyrlk_with_cells): workgroups [0, a.capacity) each track a feature,
+// the rest each own a rectangle of detector cells (harris_cells.hpp).  PyrLK's waves come first -- they are the long ones,
+// and a launch of them alone ends with compute units idling behind its slowest waves; the cell-pass waves fill that tail.
+template <int NSEG, int WMAX, bool FULL>
+__device__ __forceinline__ void pyrlk_cells_wave(const LKArgs &a, const CornerArgs &c)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.x < a.capacity) pyrlk_wave<NSEG, WMAX, true, FULL>(a, blockIdx.x, smem);
+    else harris_cells_wave(c, blockIdx.x - a.capacity, gridDim.x - a.capacity, reinterpret_cast<uint8_t *>(smem));
+}
+template <int NSEG, int WMAX, bool FULL>
+__global__ __launch_bounds__(64) void k_pyrlk_cells(LKArgs a, CornerArgs c)
+{
+    pyrlk_cells_wave<NSEG, WMAX, FULL>(a, c);
+}
+template <int NSEG, int WMAX, bool FULL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(52))) void k_pyrlk_cells_104(LKArgs a, CornerArgs c)
+{
+    pyrlk_cells_wave<NSEG, WMAX, FULL>(a, c);
 }
 
 template <int NSEG, int WMAX>
-hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipStream_t stream)
+hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipStream_t stream, const CornerArgs *cells = nullptr,
+                         uint32_t cell_blocks = 0, size_t cell_lds = 0)
 {
     constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;
     constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
@@ -552,7 +582,20 @@ hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipSt
     // every active lane has a whole segment of NSEG pixels: the specialisation without per-pixel selects (+ a zero strip in LDS)
     const bool full = a.seglen == NSEG && a.segs * a.seglen == a.win;
     const size_t lds = (size_t)(TILE_FLOATS + (full ? 3 * TS + PS + 32 : 0)) * sizeof(float);
-    const dim3 grid(capacity), block(64);
+    const dim3 block(64);
+    if (cells) {   // aligned pyramids only (pyrlk_cells_fusable)
+        const dim3 grid(capacity + cell_blocks);
+        const size_t both = lds > cell_lds ? lds : cell_lds;
+        if constexpr (NSEG == 7) {
+            if (full) hipLaunchKernelGGL((k_pyrlk_cells_104<NSEG, WMAX, true>), grid, block, both, stream, a, *cells);
+            else hipLaunchKernelGGL((k_pyrlk_cells_104<NSEG, WMAX, false>), grid, block, both, stream, a, *cells);
+        } else {
+            if (full) hipLaunchKernelGGL((k_pyrlk_cells<NSEG, WMAX, true>), grid, block, both, stream, a, *cells);
+            else hipLaunchKernelGGL((k_pyrlk_cells<NSEG, WMAX, false>), grid, block, both, stream, a, *cells);
+        }
+        return hipGetLastError();
+    }
+    const dim3 grid(capacity);
     if constexpr (NSEG == 7) {
         if (aligned && full) hipLaunchKernelGGL((k_pyrlk_104<NSEG, WMAX, true, true>), grid, block, lds, stream, a);
         else if (aligned) hipLaunchKernelGGL((k_pyrlk_104<NSEG, WMAX, true, false>), grid, block, lds, stream, a);
@@ -567,15 +610,18 @@ hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipSt
     return hipGetLastError();
 }
 
-}  // namespace
-
-hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
+bool pyramids_aligned(const PyrLKParams &p)
 {
-    if (p.capacity == 0) return hipSuccess;
     bool aligned = true;
     for (uint32_t l = 0; l < p.prev.levels; ++l)
         aligned = aligned && ((uintptr_t)p.prev.ptr[l] % 4u == 0) && (p.prev.pitch[l] % 4u == 0) &&
                   ((uintptr_t)p.curr.ptr[l] % 4u == 0) && (p.curr.pitch[l] % 4u == 0);
+    return aligned;
+}
+
+hipError_t launch_lk(const PyrLKParams &p, hipStream_t stream, const CornerArgs *cells, uint32_t cell_blocks, size_t cell_lds)
+{
+    const bool aligned = pyramids_aligned(p);
     LKArgs a{};
     a.prev = p.prev; a.curr = p.curr; a.item = p.item;
     a.prev_pts = p.prev_pts; a.prev_count = p.prev_count; a.estimates = p.estimates;
@@ -592,10 +638,34 @@ hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
     a.segs = (win + a.seglen - 1) / a.seglen;
     a.lanes = a.segs * win;
 
-    if (win <= 10) return launch_bucket<2, 10>(a, aligned, p.capacity, stream);
-    if (win <= 16) return launch_bucket<4, 16>(a, aligned, p.capacity, stream);
-    if (win <= 21) return launch_bucket<7, 21>(a, aligned, p.capacity, stream);
-    return launch_bucket<16, 32>(a, aligned, p.capacity, stream);
+    if (win <= 10) return launch_bucket<2, 10>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
+    if (win <= 16) return launch_bucket<4, 16>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
+    if (win <= 21) return launch_bucket<7, 21>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
+    return launch_bucket<16, 32>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
+}
+
+}  // namespace
+
+hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
+{
+    if (p.capacity == 0) return hipSuccess;
+    return launch_lk(p, stream, nullptr, 0, 0);
+}
+
+bool pyrlk_cells_fusable(const PyrLKParams &lk, const CornerTrackParams &ct)
+{
+    return ct.detector == kHarris && ct.cell_size != 0u && ct.image.width <= 65535u && ct.image.height <= 65535u &&
+           lk.capacity != 0u && pyramids_aligned(lk);
+}
+
+hipError_t launch_pyrlk_with_cells(const PyrLKParams &lk, const CornerTrackParams &ct, hipStream_t stream)
+{
+    if (!pyrlk_cells_fusable(lk, ct)) return hipErrorInvalidValue;
+    CornerArgs c{};
+    uint32_t blocks = 0;
+    size_t lds = 0;
+    harris_cells_setup(ct, c, blocks, lds);
+    return launch_lk(lk, stream, &c, blocks, lds);
 }
 
 }  // namespace vsa
