@@ -36,7 +36,29 @@
 namespace vsa {
 namespace {
 
-constexpr int LK_MARGIN = 4;  // search tile margin M (pixels) on each side of the window
+constexpr int LK_MARGIN = 3;  // search tile margin M (pixels) on each side of the window (a position that walks further restages the tile)
+
+// Staged-tile geometry.  A tile row of `px` pixels starting anywhere in a dword needs (px + 6) / 4 aligned dwords.  That count is
+// rounded up to a power of two when it costs no extra load per lane: which (row, dword) a lane's i-th slot is then comes from a
+// shift and a mask of the lane number, with constant strides between slots (21 x 21: 8 dwords for both tiles, 3 + 4 loads per lane
+// and level), instead of a division by 7 or 9 for each of the eight slots at every issue and commit.
+constexpr int ceil_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+constexpr int tile_slots_per_lane(int rows, int nd) { return (rows * nd + 63) / 64; }
+constexpr int tile_dwords(int rows, int px)
+{
+    const int nd = (px + 6) >> 2, p2 = ceil_pow2(nd);
+    return (p2 <= 64 && tile_slots_per_lane(rows, p2) <= tile_slots_per_lane(rows, nd)) ? p2 : nd;
+}
+constexpr int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+template <int WMAX>
+struct LKTiles {
+    static constexpr int PROWS = WMAX + 3, JROWS = WMAX + 1 + 2 * LK_MARGIN;                  // template / search tile rows (= pixels per row)
+    static constexpr int NDP = tile_dwords(PROWS, PROWS), NDJ = tile_dwords(JROWS, JROWS);    // dwords per tile row
+    static constexpr int NLP = tile_slots_per_lane(PROWS, NDP), NLJ = tile_slots_per_lane(JROWS, NDJ);
+    static constexpr int PS4 = NDP | 1, JS4 = NDJ | 1;                                        // LDS row strides (float4), odd
+    static constexpr int PS = 4 * PS4, JS = 4 * JS4;                                          // ... in floats
+    static constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * PS, JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * JS;   // tile regions
+};
 
 struct LKArgs {
     PyramidView prev, curr;
@@ -148,18 +170,23 @@ __device__ __forceinline__ void tile_issue(TileRegs<NL> &t, int lane, const uint
                                            int w, int h, int x0, int y0, bool fast)
 {
     const int xa = x0 & ~3;
-    lane = opaque(lane);
+    constexpr bool POW2 = (ND & (ND - 1)) == 0;
+    lane = opaque(lane);   // rows and offsets of the slots are re-derived here (an add each), not held across the level loop
     if (fast) {   // wave-uniform
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int idx = lane + 64 * i, row = idx / ND, col4 = 4 * (idx - row * ND);
+            const int idx = lane + 64 * i;
+            const int row = POW2 ? (lane >> ilog2(ND)) + (64 / ND) * i : idx / ND;
+            const int col4 = POW2 ? 4 * (lane & (ND - 1)) : 4 * (idx - row * ND);
             const int gy = min(max(y0 + row, 0), h - 1);
             t.v[i] = *reinterpret_cast<const uint32_t *>(img + ((uint32_t)gy * pitch + (uint32_t)(xa + col4)));
         }
     } else {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int idx = lane + 64 * i, row = idx / ND, col4 = 4 * (idx - row * ND);
+            const int idx = lane + 64 * i;
+            const int row = POW2 ? (lane >> ilog2(ND)) + (64 / ND) * i : idx / ND;
+            const int col4 = POW2 ? 4 * (lane & (ND - 1)) : 4 * (idx - row * ND);
             const int gy = min(max(y0 + row, 0), h - 1);
             const uint8_t *rowp = img + (uint32_t)gy * pitch;
             const int X = xa + col4;
@@ -174,12 +201,14 @@ template <int NL, int ND, int LS4>
 __device__ __forceinline__ void tile_commit(const TileRegs<NL> &t, int lane, float *dst)
 {
     float4 *d4 = reinterpret_cast<float4 *>(dst);
-    lane = opaque(lane);
+    constexpr bool POW2 = (ND & (ND - 1)) == 0;
+    lane = opaque(lane);   // rows and offsets of the slots are re-derived here (an add each), not held across the level loop
+    const int slot0 = (lane >> ilog2(ND)) * LS4 + (lane & (ND - 1));   // POW2: slot i lies (64 / ND) rows further down
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
         const int idx = lane + 64 * i, row = idx / ND;
         const uint32_t v = t.v[i];
-        d4[row * LS4 + (idx - row * ND)] = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
+        d4[POW2 ? slot0 + (64 / ND) * LS4 * i : row * LS4 + (idx - row * ND)] = make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
     }
 }
 
@@ -195,11 +224,9 @@ __device__ __forceinline__ bool tile_inside(int x0, int n, int nd, int w, uint32
 template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
 __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, float *smem)
 {
-    constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;   // dwords per tile row
-    constexpr int PS4 = NDP | 1, JS4 = NDJ | 1;                                            // LDS row strides (float4), odd
-    constexpr int PS = 4 * PS4, JS = 4 * JS4;                                              // ... in floats
-    constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
-    constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * PS, JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * JS;   // tile regions
+    using G = LKTiles<WMAX>;
+    constexpr int NDP = G::NDP, NDJ = G::NDJ, NLP = G::NLP, NLJ = G::NLJ;
+    constexpr int PS4 = G::PS4, JS4 = G::JS4, PS = G::PS, JS = G::JS, PFLOATS = G::PFLOATS, JFLOATS = G::JFLOATS;
     constexpr int TS = (WMAX + NSEG + 2) | 1;                                              // row stride of the resampled template tile
     constexpr int TBASE = PFLOATS + 64;                                                    // it follows the template tile and its slack; the
                                                                                            // search tile, committed after the pass, may overlap it
@@ -261,9 +288,11 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
     if (idle) { row = 0; x0 = 0; cnt = 0; }
     // FULL: an idle lane resamples and differentiates zeros (its template reads and its T row live in the zero strip),
     // so its I, Ix, Iy are exact zeros without any select; its search-tile reads stay on real pixels (finite x 0)
-    const int lbaseP = (FULL && idle) ? TILE_FLOATS - PS : row * PS + x0;                       // reads start at TILE_FLOATS + (p_x0 & 3)
-    const int lbaseJ = row * JS + x0;
-    const int lbaseT = (FULL && idle) ? TILE_FLOATS + PS + NSEG + 8 - TBASE : row * TS + x0;    // T rows behind the strip's template part
+    // Where a lane's segment starts in each tile.  Derived where they are used, once per level, from a copy of the row number
+    // the compiler cannot see through -- held across the level loop they are three of the 104 registers the kernel is capped at.
+    auto lane_base_p = [&]() { return (FULL && idle) ? TILE_FLOATS - PS : opaque(row) * PS + x0; };   // reads start at TILE_FLOATS + (p_x0 & 3)
+    auto lane_base_j = [&]() { return opaque(row) * JS + x0; };
+    auto lane_base_t = [&]() { return (FULL && idle) ? TILE_FLOATS + PS + NSEG + 8 - TBASE : opaque(row) * TS + x0; };   // T rows behind the strip's template part
     static_assert(PS + NSEG + 8 + 2 * TS + NSEG + 2 <= ZSTRIP, "zero strip holds an idle lane's template and T accesses");
 
     // LDS only ever holds converted pixels, resampled template values or the zeros written here (the slack a lane may
@@ -328,7 +357,8 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         // nobody uses (pixels k >= cnt are zeroed below).
         float sxx = 0.0f, sxy = 0.0f, syy = 0.0f;
         {
-            const float *q = P + lbaseP + (p_x0 & 3) + PS;   // P(row + 1 + rr, x0 + c) = q[rr*PS + c]
+            const float *q = P + lane_base_p() + (p_x0 & 3) + PS;   // P(row + 1 + rr, x0 + c) = q[rr*PS + c]
+            const int lbaseT = lane_base_t();
             float tc[NSEG + 2];
             {
                 float vp = fmaf(ay, q[PS] - q[0], q[0]);
@@ -342,7 +372,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
             float *tw = T + lbaseT + TS;                       // T(row + 1, x0 + j)
 #pragma unroll
             for (int j = 0; j < NSEG + 2; ++j) tw[j] = tc[j];
-            for (int e = lane; e < 2 * (win + 2); e += 64) {   // rows R = 0 and R = win+1
+            for (int e = opaque(lane); e < 2 * (win + 2); e += 64) {   // rows R = 0 and R = win+1
                 const int far = e >= win + 2;
                 const int C = e - (far ? win + 2 : 0), R = far ? win + 1 : 0;
                 const float *pe = P + (p_x0 & 3) + R * PS + C;
@@ -432,7 +462,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
             // the integer position moves: the iteration loop is bound by the LDS pipe (16 dword reads per lane with 2-way
             // bank conflicts; profiles/r02_kernel_experiments.txt), and most iterations now read nothing.
             if (jx != cached_jx || jy != cached_jy) {   // wave-uniform
-                const float *jt = J + lbaseJ + (oy * JS + (jx0 & 3) + ox);
+                const float *jt = J + lane_base_j() + (oy * JS + (jx0 & 3) + ox);
 #pragma unroll
                 for (int k = 0; k < NSEG + 1; ++k) { ja[k] = jt[k]; jb[k] = jt[JS + k]; }
                 cached_jx = jx; cached_jy = jy;
@@ -474,7 +504,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
                     tile_commit<NLJ, NDJ, JS4>(tj, lane, J);
                     __syncthreads();
                 }
-                const float *jt = J + lbaseJ + (oy * JS + (jx0 & 3) + ox);
+                const float *jt = J + lane_base_j() + (oy * JS + (jx0 & 3) + ox);
                 float cp = fmaf(by, jt[JS] - jt[0], jt[0]);
                 float e = 0.0f;
 #pragma unroll
@@ -572,10 +602,8 @@ template <int NSEG, int WMAX>
 hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipStream_t stream, const CornerArgs *cells = nullptr,
                          uint32_t cell_blocks = 0, size_t cell_lds = 0)
 {
-    constexpr int NDP = (WMAX + 3 + 6) >> 2, NDJ = (WMAX + 1 + 2 * LK_MARGIN + 6) >> 2;
-    constexpr int NLP = ((WMAX + 3) * NDP + 63) / 64, NLJ = ((WMAX + 1 + 2 * LK_MARGIN) * NDJ + 63) / 64;
-    constexpr int PS = 4 * (NDP | 1);
-    constexpr int PFLOATS = ((NLP * 64 + NDP - 1) / NDP) * PS, JFLOATS = ((NLJ * 64 + NDJ - 1) / NDJ) * 4 * (NDJ | 1);
+    using G = LKTiles<WMAX>;
+    constexpr int PS = G::PS, PFLOATS = G::PFLOATS, JFLOATS = G::JFLOATS;
     constexpr int TS = (WMAX + NSEG + 2) | 1;
     constexpr int TEND = PFLOATS + 64 + (WMAX + 3) * TS;   // template tile + zeroed slack + T tile; the search tile overlaps T
     constexpr int TILE_FLOATS = (JFLOATS + 64 > TEND) ? JFLOATS + 64 : TEND;
