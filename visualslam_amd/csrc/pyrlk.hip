@@ -358,7 +358,9 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         float sxx = 0.0f, sxy = 0.0f, syy = 0.0f;
         {
             const float *q = P + lane_base_p() + (p_x0 & 3) + PS;   // P(row + 1 + rr, x0 + c) = q[rr*PS + c]
-            const int lbaseT = lane_base_t();
+            // (the T tile's offset goes into the base register: folded into the instructions' 8-bit dword offsets it does not fit,
+            // and every ds_read2 then gets an address add of its own)
+            const float *Tl = smem + opaque(TBASE + lane_base_t());
             float tc[NSEG + 2];
             {
                 float vp = fmaf(ay, q[PS] - q[0], q[0]);
@@ -369,7 +371,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
                     vp = v;
                 }
             }
-            float *tw = T + lbaseT + TS;                       // T(row + 1, x0 + j)
+            float *tw = const_cast<float *>(Tl) + TS;          // T(row + 1, x0 + j)
 #pragma unroll
             for (int j = 0; j < NSEG + 2; ++j) tw[j] = tc[j];
             for (int e = opaque(lane); e < 2 * (win + 2); e += 64) {   // rows R = 0 and R = win+1
@@ -380,7 +382,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
                 T[R * TS + C] = fmaf(ax, vb - va, va);
             }
             __syncthreads();
-            const float *tu = T + lbaseT, *td = T + lbaseT + 2 * TS;   // T(row, x0 + j), T(row + 2, x0 + j)
+            const float *tu = Tl, *td = Tl + 2 * TS;                    // T(row, x0 + j), T(row + 2, x0 + j)
             float sm_p = 0.0f, sm_pp = 0.0f, df_p = 0.0f, df_pp = 0.0f;
 #pragma unroll
             for (int j = 0; j < NSEG + 2; ++j) {
