@@ -45,8 +45,18 @@ __device__ __forceinline__ float harris_r(int a, int b, int c, float k)
 
 // ---- Harris: one wave per rectangle of cells, lane = column ----------------------------------
 constexpr int HS_USE = 55;    // owned columns per strip: 64 lanes - 3 right halo - (3..6) left halo (dword-aligned origin)
-constexpr int HS_ROWS = 48;   // owned rows per chunk (LDS tile height - 6)
-constexpr int HS_BAND = 24;   // preferred owned rows per wave: shorter bands = more waves per SIMD
+#ifndef VSA_HS_ROWS
+#define VSA_HS_ROWS 48
+#endif
+#ifndef VSA_HS_BAND
+#define VSA_HS_BAND 36
+#endif
+constexpr int HS_ROWS = VSA_HS_ROWS;   // owned rows per chunk (LDS tile height - 6)
+// Preferred owned rows per wave.  A wave computes 6 halo rows beside the rows it owns, so taller bands mean less work in total
+// (cell 18: bands of 36 rows stream 42 rows for 36, bands of 18 stream 24 for 18: -12 % vector instructions) and fewer, longer
+// waves.  With many camera streams on the GPU the instruction count is what matters (+5 % frames/s on the 32-stream bench for 36
+// against 24; 54 gains nothing more and a stream alone loses 12 %, against 4 % for 36) -- profiles/r02_kernel_experiments.txt.
+constexpr int HS_BAND = VSA_HS_BAND;
 constexpr int HS_R = HS_ROWS + 6 + 2;   // LDS tile rows: owned + halo + the partial last triple
 constexpr int HS_NLD = (HS_R * 16 + 63) / 64;
 
