@@ -36,19 +36,19 @@ CONFIGS = {
                workload="640x480 frames, 6-level pyramid, <=2000 Harris features (cell 18, k 0.04, threshold 2000), 6x6 PyrLK window, "
                         "5 iters (data/feature_tracker_demo_config.ini)",
                bytes=dict(pyramid=409200 + 102300, detect=307200 + 16000, lk=819000 + 32000, cvt=1536000),
-               lk_kernel="k_pyrlk<2,10,true>"),
+               lk_kernel="k_pyrlk<2,10,true,false>", lk_cells_kernel="k_pyrlk_cells<2,10,false>"),
     "c2": dict(baseline_config=1, width=1920, height=1080, levels=5, capacity=4096, cell=18, win=21, iters=5,
                harris=True, harris_thresh=100.0, ring=64, streams=32,
                frames="1080p synthetic RGBX frames (seed 1234: low-pass noise + blobs, known sub-pixel drift, per-frame noise)",
                workload="1080p synthetic RGBX frames, 5-level pyramid, 4k Harris features (cell 18), 21x21 PyrLK window, 5 iters",
                bytes=dict(pyramid=2754000 + 688560, detect=2073600 + 32768, lk=5524320 + 65536, cvt=10368000),
-               lk_kernel="k_pyrlk<7,21,true>"),
+               lk_kernel="k_pyrlk_104<7,21,true,true>", lk_cells_kernel="k_pyrlk_cells_104<7,21,true>"),
     "c3": dict(baseline_config=2, width=3840, height=2160, levels=7, capacity=10000, cell=18, win=21, iters=5,
                harris=False, harris_thresh=100.0, ring=16, streams=16,
                frames="4K synthetic RGBX frames (seed 1234: low-pass noise + blobs, known sub-pixel drift, per-frame noise)",
                workload="4K synthetic RGBX frames, 7-level pyramid, FAST-9 (threshold 25) track with 10k features (cell 18), 21x21 PyrLK window, 5 iters",
                bytes=dict(pyramid=11056560 + 2764200, detect=8294400 + 80000, lk=22117200 + 160000, cvt=41472000),
-               lk_kernel="k_pyrlk<7,21,true>"),
+               lk_kernel="k_pyrlk_104<7,21,true,true>", lk_cells_kernel=None),
 }
 
 
@@ -379,8 +379,14 @@ def main():
         bytes_frame = B["pyramid"] + B["detect"] + B["lk"] + B["cvt"]
         frames = args.steps * args.streams * world
         fps = frames / elapsed
-        lk_gbs = B["lk"] / (max(lk_alone_ms, 1e-9) * 1e-3) / 1e9
-        counters = load_profile_json("frame_counters.json") if args.config == "c2" and not args.homography else None
+        # The OpenVX graph runs the HarrisTrack node's cell pass inside the PyrLK launch (vxVerifyGraph's node fusion): the dominant
+        # kernel is then PyrLK + cell pass, and its algorithmic bytes are PyrLK's plus the detector's read of level 0
+        fused = args.api == "ovx" and cfg["harris"] and cfg["lk_cells_kernel"] and not os.environ.get("VISUALSLAM_AMD_NO_FUSION")
+        lk_bytes = B["lk"] + (W * H if fused else 0)
+        lk_name = cfg["lk_cells_kernel"] if fused else cfg["lk_kernel"]
+        lk_what = "PyrLK + HarrisTrack cell pass" if fused else "PyrLK"
+        lk_gbs = lk_bytes / (max(lk_alone_ms, 1e-9) * 1e-3) / 1e9
+        counters = load_profile_json("frame_counters.json") if args.config == "c2" and not args.homography and fused else None
         lk_counters = (counters or {}).get("by_kernel", {}).get("k_pyrlk", {})
         out = {
             "metric": "frames/sec @1080p with 4k PyrLK tracks",
@@ -400,10 +406,10 @@ def main():
             # the dominant kernel against the HBM roof.  launch_ms: the kernel ALONE (stream 0 driven by itself after the
             # timed region, HIP events, 50 launches); launch_ms_in_timed_region: the same events while the other streams'
             # kernels share the GPU (mean concurrency ~2.3, profiles/r02_bench_concurrency.txt) -- longer, not slower work
-            "roofline": {"kernel": f"{cfg['lk_kernel']} (PyrLK, {cfg['capacity']} points x {cfg['levels']} levels, {cfg['win']}x{cfg['win']})",
+            "roofline": {"kernel": f"{lk_name} ({lk_what}, {cfg['capacity']} points x {cfg['levels']} levels, {cfg['win']}x{cfg['win']})",
                          "bound": "hbm", "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
                          "traffic": lk_counters.get("hbm_bytes"), "launch_ms": lk_alone_ms,
-                         "launch_ms_in_timed_region": lk_loaded_ms, "algorithmic_bytes_per_launch": B["lk"]},
+                         "launch_ms_in_timed_region": lk_loaded_ms, "algorithmic_bytes_per_launch": lk_bytes},
         }
         if counters and lk_counters.get("valu_wave_instructions"):
             # what actually bounds this kernel and the path: vector-instruction issue.  Wave-instructions
@@ -411,7 +417,7 @@ def main():
             # f32 FMA issue rate measured on this GPU
             peak = counters["peak_wave_instructions_per_ns"]
             lk_rate = lk_counters["valu_wave_instructions"] / (lk_alone_ms * 1e6)
-            out["roofline_valu"] = {"kernel": cfg["lk_kernel"], "bound": "valu issue", "wave_instructions_per_launch": lk_counters["valu_wave_instructions"],
+            out["roofline_valu"] = {"kernel": lk_name, "bound": "valu issue", "wave_instructions_per_launch": lk_counters["valu_wave_instructions"],
                                     "achieved": lk_rate, "peak": peak, "unit": "G wave-instructions/s", "frac": lk_rate / peak,
                                     "launch_ms": lk_alone_ms}
             per_frame = counters["valu_wave_instructions_per_frame"]

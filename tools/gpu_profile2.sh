@@ -2,7 +2,7 @@
 # usage: gpu_profile2.sh TAG -- the profiles behind bench.py's roofline objects (round 2):
 #   1. rocprofv3 --kernel-trace --stats of the default bench command (short run) + its concurrency timeline
 #   2. the same of a single-stream run (the kernels ALONE: what roofline.launch_ms must agree with)
-#   3. PMC passes over one stream's frames (tools/prof_kernels.py frame): SQ instruction counts, LDS, FETCH_SIZE, WRITE_SIZE
+#   3. PMC passes over one stream's frames through the OpenVX graph (tools/prof_kernels.py graph): SQ instruction counts, LDS, FETCH_SIZE, WRITE_SIZE
 # Every GPU step has its own time limit; the first failure ends the script.
 set -euo pipefail
 TAG=${1:-r02p}
@@ -24,7 +24,7 @@ for CS in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VM
           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
           "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d "$OUT/pmc$i" -o k -- python3 "$GRAFT_REPO_ROOT/tools/prof_kernels.py" frame 20 > "$OUT/pmc$i.log" 2>&1
+  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d "$OUT/pmc$i" -o k -- python3 "$GRAFT_REPO_ROOT/tools/prof_kernels.py" graph 20 > "$OUT/pmc$i.log" 2>&1
   rm -f "$(find "$OUT/pmc$i" -name 'k_kernel_trace.csv' | head -1)"
 done
 python3 - "$OUT" <<'PY'

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Run one primitive of the 1080p workload repeatedly (for rocprofv3 --kernel-trace / --pmc passes).
-usage: prof_kernels.py {lk|harris|pyramid|cvt|frame} [reps]"""
+usage: prof_kernels.py {lk|harris|pyramid|cvt|frame|graph} [reps]
+  frame: whole frames through the thin layer (five launches: nvxcu primitives cannot fuse)
+  graph: whole frames of ONE camera stream through the OpenVX graph as bench.py builds it (the fused launches)"""
 import os
 import sys
 
@@ -18,6 +20,23 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 W, H = 1920, 1080
 p = Params(pyr_levels=5, lk_win_size=21, array_capacity=4096)
 base = synth.base_frame(W, H, 1234)
+if what == "graph":
+    from visualslam_amd import ovx
+    from visualslam_amd.vx_tracker import VxFeatureTracker
+    L = ovx.lib()
+    ctx = L.vxCreateContext()
+    ovx.check(L.vxGetStatus(ctx), "vxCreateContext")
+    ring = []
+    for t in range(4):
+        img = L.vxCreateImage(ctx, W, H, ovx.VX_DF_IMAGE_RGBX)
+        ovx.write_image(img, synth.to_rgbx(synth.gray_frame(base, t, 1234)))
+        ring.append(img)
+    trk = VxFeatureTracker(ctx, p, W, H, ring[0], None)
+    for k in range(reps + 2):
+        trk.track(ring[(k + 1) % 4], None)
+    torch.cuda.synchronize()
+    print("done", what, reps)
+    sys.exit(0)
 frames = [DeviceImage(W, H, nvxcu.NVXCU_DF_IMAGE_RGBX).upload(synth.to_rgbx(synth.gray_frame(base, t))) for t in range(2)]
 trk = ThinFeatureTracker(p, W, H)
 trk.init(frames[0].desc)
