@@ -140,6 +140,21 @@ def load_profile_json(name):
         return json.load(f)
 
 
+def profiled_launch_ms(kernel):
+    """average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of a single-stream run of this bench
+    (profiles/r02_single_stream_kernel_stats.csv): the kernel's own begin-to-end time, without the few microseconds of dispatch
+    latency that the HIP events around a launch include"""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r02_single_stream_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    want = kernel.replace(" ", "")
+    for r in csv.DictReader(open(path)):
+        if want in r["Name"].replace(" ", ""):
+            return float(r["AverageNs"]) * 1e-6
+    return None
+
+
 def launch_ranks(args, argv):
     """--gpus N with no launcher: start the N ranks as fresh child processes (this parent never touches a GPU, and
     nothing that has initialised a GPU is ever re-executed).  Rank 0's stdout carries the JSON line."""
@@ -409,7 +424,8 @@ def main():
             "roofline": {"kernel": f"{lk_name} ({lk_what}, {cfg['capacity']} points x {cfg['levels']} levels, {cfg['win']}x{cfg['win']})",
                          "bound": "hbm", "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
                          "traffic": lk_counters.get("hbm_bytes"), "launch_ms": lk_alone_ms,
-                         "launch_ms_in_timed_region": lk_loaded_ms, "algorithmic_bytes_per_launch": lk_bytes},
+                         "launch_ms_in_timed_region": lk_loaded_ms, "algorithmic_bytes_per_launch": lk_bytes,
+                         "launch_ms_rocprof_single_stream": profiled_launch_ms(lk_name) if args.config == "c2" and not args.homography else None},
         }
         if counters and lk_counters.get("valu_wave_instructions"):
             # what actually bounds this kernel and the path: vector-instruction issue.  Wave-instructions
