@@ -587,7 +587,12 @@ __device__ __forceinline__ void pyrlk_cells_wave(const LKArgs &a, const CornerAr
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (blockIdx.x < a.capacity) pyrlk_wave<NSEG, WMAX, true, FULL>(a, blockIdx.x, smem);
-    else harris_cells_wave(c, blockIdx.x - a.capacity, gridDim.x - a.capacity, reinterpret_cast<uint8_t *>(smem));
+    else {
+        // the cell-pass waves start in the launch's tail, beside PyrLK's slowest waves: with issue priority over them the
+        // launch alone ends 2.4 us earlier (40.5 against 42.9 us); the other order (cell pass first) changes nothing
+        __builtin_amdgcn_s_setprio(3);
+        harris_cells_wave(c, blockIdx.x - a.capacity, gridDim.x - a.capacity, reinterpret_cast<uint8_t *>(smem));
+    }
 }
 template <int NSEG, int WMAX, bool FULL>
 __global__ __launch_bounds__(64) void k_pyrlk_cells(LKArgs a, CornerArgs c)
