@@ -224,7 +224,12 @@ def main():
     from visualslam_amd import nvxcu
     from visualslam_amd.thin_tracker import Params
 
+    json_fd = None
     if world > 1:
+        # stdout carries the ONE JSON line: what libraries print there from native code (Gloo's connection banner) goes to stderr
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -447,7 +452,12 @@ def main():
                                  "matrix_stream0": [float(x) for x in H_.T.reshape(-1)]}
         if not args.no_cpu_baseline and world == 1 and not args.homography:
             out["cpu_baseline"] = cpu_baseline(host_frames, params)
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
+        if json_fd is not None:
+            os.dup2(2, 1)
     if driver:
         drv.vsa_driver_destroy(driver)
     barrier(world)
