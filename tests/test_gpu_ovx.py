@@ -449,3 +449,48 @@ def test_fusion_is_skipped_when_a_node_reads_the_grey_image_before_the_pyramid(c
     np.testing.assert_array_equal(ovx.read_image(copy), want[0])
     lv2 = L.vxGetPyramidLevel(pyr, 2)
     np.testing.assert_array_equal(ovx.read_image(lv2), want[2])
+
+
+def _run_sequence(ctx, p, w, h, frames, **kw):
+    imgs = []
+    for f in frames:
+        img = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+        ovx.write_image(img, f)
+        imgs.append(img)
+    trk = VxFeatureTracker(ctx, p, w, h, imgs[0], None, **kw)
+    ref = OracleTracker(p)
+    ref.init(frames[0], None)
+    np.testing.assert_array_equal(trk.merged(), ref.prev_pts)
+    for t in range(1, len(frames)):
+        trk.track(imgs[t], None)
+        old, cur = ref.track(frames[t], None)
+        assert trk.prev().tobytes() == old.tobytes(), f"frame {t}: previous features"
+        assert trk.curr().tobytes() == cur.tobytes(), f"frame {t}: tracked features"
+        assert trk.merged().tobytes() == ref.prev_pts.tobytes(), f"frame {t}: merged features"
+    return trk
+
+
+@pytest.mark.parametrize("win", [6, 10, 16, 21, 32])
+@pytest.mark.parametrize("fusion", [True, False])
+def test_harris_cell_pass_in_the_pyrlk_launch_or_not(gpu, monkeypatch, win, fusion):
+    """vxVerifyGraph lets the HarrisTrack node's cell pass (which reads only the image) run inside the PyrLK node's launch
+    (one fused kernel per PyrLK window bucket); VISUALSLAM_AMD_NO_FUSION keeps the two nodes' launches apart.  Either way
+    every frame's tracked and merged features are the oracle's, bit for bit (feature_tracker.cpp:402-422 is the graph)."""
+    if not fusion:
+        monkeypatch.setenv("VISUALSLAM_AMD_NO_FUSION", "1")
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    try:
+        w, h = 643, 481                                       # odd sizes: partial cell blocks on both edges
+        p = Params(pyr_levels=4, lk_win_size=win, use_harris_detector=True, harris_thresh=2000.0, array_capacity=1500)
+        _run_sequence(c, p, w, h, _frames(w, h, 4, seed=40 + win))
+    finally:
+        assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
+
+
+def test_cell_pass_is_not_fused_when_its_image_is_written_after_pyrlk_starts(ctx):
+    """the detector reads a copy of the grey frame made by a node that runs between PyrLK and the detector: the cell pass must
+    wait for it (run fused, it would see the previous frame's copy)"""
+    w, h = 320, 240
+    p = Params(pyr_levels=3, lk_win_size=21, use_harris_detector=True, harris_thresh=2000.0, array_capacity=600)
+    _run_sequence(ctx, p, w, h, _frames(w, h, 4, seed=77), detect_on_copy=True)

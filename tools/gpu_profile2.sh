@@ -18,6 +18,9 @@ gzip -f "$(find "$OUT/bench" -name 'bench_kernel_trace.csv' | head -1)"   # kept
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/single" -o single -- python3 "$GRAFT_REPO_ROOT/bench.py" --streams 1 --steps 300 --warmup 20 --no-cpu-baseline > "$OUT/single_under_rocprof.json" 2> "$OUT/single.err"
 cat "$OUT/single_under_rocprof.json" | cut -c1-200
 rm -f "$(find "$OUT/single" -name 'single_kernel_trace.csv' | head -1)"
+# 2b. the thin layer's five launches alone (nvxcu primitives cannot fuse): PyrLK by itself, the Harris cell pass by itself
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/thin" -o thin -- python3 "$GRAFT_REPO_ROOT/tools/prof_kernels.py" frame 200 > "$OUT/thin.log" 2>&1
+rm -f "$(find "$OUT/thin" -name 'thin_kernel_trace.csv' | head -1)"
 i=0
 for CS in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" \
           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" \

@@ -45,18 +45,16 @@ __device__ __forceinline__ float harris_r(int a, int b, int c, float k)
 
 // ---- Harris: one wave per rectangle of cells, lane = column ----------------------------------
 constexpr int HS_USE = 55;    // owned columns per strip: 64 lanes - 3 right halo - (3..6) left halo (dword-aligned origin)
-#ifndef VSA_HS_ROWS
-#define VSA_HS_ROWS 48
-#endif
-#ifndef VSA_HS_BAND
-#define VSA_HS_BAND 36
-#endif
-constexpr int HS_ROWS = VSA_HS_ROWS;   // owned rows per chunk (LDS tile height - 6)
-// Preferred owned rows per wave.  A wave computes 6 halo rows beside the rows it owns, so taller bands mean less work in total
-// (cell 18: bands of 36 rows stream 42 rows for 36, bands of 18 stream 24 for 18: -12 % vector instructions) and fewer, longer
-// waves.  With many camera streams on the GPU the instruction count is what matters (+5 % frames/s on the 32-stream bench for 36
-// against 24; 54 gains nothing more and a stream alone loses 12 %, against 4 % for 36) -- profiles/r02_kernel_experiments.txt.
-constexpr int HS_BAND = VSA_HS_BAND;
+constexpr int HS_ROWS = 48;   // owned rows per chunk (LDS tile height - 6)
+// Preferred owned rows per wave (a launch parameter: the kernel takes the cell block from its arguments).  A wave computes 6 halo
+// rows beside the rows it owns, so taller bands mean less work in total (cell 18: bands of 36 rows stream 42 rows for 36, bands of
+// 18 stream 24 for 18: -12 % vector instructions) and fewer, longer waves.
+//   HS_BAND       the cell pass launched by itself (thin layer, immediate mode): short waves, the launch ends sooner (12 us at
+//                 1080p against 17 us with 36-row bands);
+//   HS_BAND_FUSED the cell pass inside the PyrLK launch of a graph: with many camera streams on the GPU the instruction count is
+//                 what matters (+5 % frames/s on the 32-stream bench for 36 against 24; 54 gains nothing more) --
+//                 profiles/r02_kernel_experiments.txt.
+constexpr int HS_BAND = 24, HS_BAND_FUSED = 36;
 constexpr int HS_R = HS_ROWS + 6 + 2;   // LDS tile rows: owned + halo + the partial last triple
 constexpr int HS_NLD = (HS_R * 16 + 63) / 64;
 
@@ -255,7 +253,7 @@ inline void cell_block(uint32_t cs, int span_x, int span_y, int &nbx, int &nby)
 }
 
 // grid and LDS of the cell pass for an image (host side)
-inline void harris_cells_setup(const CornerTrackParams &p, CornerArgs &a, uint32_t &blocks, size_t &lds)
+inline void harris_cells_setup(const CornerTrackParams &p, CornerArgs &a, uint32_t &blocks, size_t &lds, int band = HS_BAND)
 {
     const uint32_t cs = p.cell_size;
     a = CornerArgs{};
@@ -264,7 +262,7 @@ inline void harris_cells_setup(const CornerTrackParams &p, CornerArgs &a, uint32
     a.cs = (int)cs;
     a.ncx = (int)((p.image.width + cs - 1) / cs);
     a.ncy = (int)((p.image.height + cs - 1) / cs);
-    cell_block(cs, HS_USE, HS_BAND, a.nbx, a.nby);
+    cell_block(cs, HS_USE, band, a.nbx, a.nby);
     a.k = p.harris_k; a.thr = p.threshold;
     a.fast_n = (int)p.fast_n; a.fast_t = (int)p.threshold;
     a.cell_best = reinterpret_cast<uint64_t *>(p.scratch);

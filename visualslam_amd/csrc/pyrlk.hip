@@ -699,7 +699,7 @@ hipError_t launch_pyrlk_with_cells(const PyrLKParams &lk, const CornerTrackParam
     CornerArgs c{};
     uint32_t blocks = 0;
     size_t lds = 0;
-    harris_cells_setup(ct, c, blocks, lds);
+    harris_cells_setup(ct, c, blocks, lds, HS_BAND_FUSED);
     return launch_lk(lk, stream, &c, blocks, lds);
 }
 

@@ -9,9 +9,11 @@ L = ovx.lib()
 class VxFeatureTracker:
     """call-for-call transcription of FeatureTrackerImpl (feature_tracker.cpp:127-449)"""
 
-    def __init__(self, ctx, p, w, h, first_frame, mask, homography=False):
+    def __init__(self, ctx, p, w, h, first_frame, mask, homography=False, detect_on_copy=False):
         """homography=True appends the video stabilizer's / SFM sample's next stage to the same graph
-        (demos/video_stabilizer/stabilizer.cpp:264-273): nvxFindHomographyNode on the PyrLK matches"""
+        (demos/video_stabilizer/stabilizer.cpp:264-273): nvxFindHomographyNode on the PyrLK matches.
+        detect_on_copy=True (tests): the detector reads a copy of the grey frame that an nvxCopyImageNode created AFTER the
+        PyrLK node makes, i.e. a graph in which the detector's input is not ready when PyrLK starts"""
         self.ctx, self.p = ctx, p
         pex = L.vxCreatePyramid(ctx, p.pyr_levels, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
         self.pyr_delay = L.vxCreateDelay(ctx, pex, 2)
@@ -31,10 +33,15 @@ class VxFeatureTracker:
                                            L.vxGetReferenceFromDelay(self.pts_delay, -1), L.vxGetReferenceFromDelay(self.pts_delay, -1),
                                            self.kp_curr, ovx.VX_TERM_CRITERIA_BOTH, eps, it, est, p.lk_win_size)
         out = L.vxGetReferenceFromDelay(self.pts_delay, 0)
+        det_in = gray
+        if detect_on_copy:
+            det_in = self.det_copy = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
+            self.copy = L.nvxCopyImageNode(self.g, gray, det_in)
+            assert L.vxGetStatus(self.copy) == ovx.VX_SUCCESS
         if p.use_harris_detector:
-            self.det = L.nvxHarrisTrackNode(self.g, gray, out, mask, self.kp_curr, p.harris_k, p.harris_thresh, p.detector_cell_size, None)
+            self.det = L.nvxHarrisTrackNode(self.g, det_in, out, mask, self.kp_curr, p.harris_k, p.harris_thresh, p.detector_cell_size, None)
         else:
-            self.det = L.nvxFastTrackNode(self.g, gray, out, mask, self.kp_curr, p.fast_type, p.fast_thresh, p.detector_cell_size, None)
+            self.det = L.nvxFastTrackNode(self.g, det_in, out, mask, self.kp_curr, p.fast_type, p.fast_thresh, p.detector_cell_size, None)
         self.hg = self.hg_matrix = self.hg_mask = None
         if homography:
             self.hg_matrix = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
