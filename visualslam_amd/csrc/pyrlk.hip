@@ -36,6 +36,9 @@
 namespace vsa {
 namespace {
 
+#ifndef VSA_LK_VGPR_HALF
+#define VSA_LK_VGPR_HALF 52    // amdgpu_num_vgpr argument of the 21 x 21 kernels: half of the register cap (see k_pyrlk_104)
+#endif
 constexpr int LK_MARGIN = 3;  // search tile margin M (pixels) on each side of the window (a position that walks further restages the tile)
 
 // Staged-tile geometry.  A tile row of `px` pixels starting anywhere in a dword needs (px + 6) / 4 aligned dwords.  That count is
@@ -336,7 +339,14 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         const float ax = ux - floorf(ux), ay = uy - floorf(uy);
         vx = 0.0f; vy = 0.0f;
 
-        // search tile around the prediction: its loads fly while the template is resampled
+        // Search tile around the prediction: its loads fly while the template is resampled.  The compiler's wait counts are
+        // conservative across this loop's branches: it waits for ALL outstanding loads before it commits a tile.  So the
+        // template tile's registers are claimed here, before the search tile's loads are issued (their loads were issued a
+        // level ago and have long landed: this wait is free, and the commit below then needs none), and the next level's
+        // template loads are issued only after the search tile is committed.  Before, each commit found younger loads in
+        // flight and exposed their whole memory latency at every level (phase stamps: 2.2 k + 1.3 k of a level's 9.3 k cycles).
+#pragma unroll
+        for (int i = 0; i < NLP; ++i) asm volatile("" : "+v"(tp.v[i]));
         int jx0 = (int)floorf(ux + gx) - half - LK_MARGIN;
         int jy0 = (int)floorf(uy + gy) - half - LK_MARGIN;
         tile_issue<NLJ, NDJ>(tj, lane, jp, jpitch, lw, lh, jx0, jy0, ALIGNED && tile_inside(jx0, JW, NDJ, lw, jpitch));
@@ -408,15 +418,17 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         wave_sum3(sxx, sxy, syy, lane_bit0, lane_bit1, Gxx, Gxy, Gyy);
         LK_PHASE(1);
 
-        // next level's template loads fly while this level iterates
-        if (L > 0) {
-            const float sn = 1.0f / (float)(1u << (L - 1));
-            p_x0 = (int)floorf(px * sn) - half - 1;
-            const int p_y0 = (int)floorf(py * sn) - half - 1;
-            const int nw = (int)a.prev.width[L - 1];
-            tile_issue<NLP, NDP>(tp, lane, a.prev.ptr[L - 1], a.prev.pitch[L - 1], nw, (int)a.prev.height[L - 1], p_x0, p_y0,
-                       ALIGNED && tile_inside(p_x0, PW, NDP, nw, a.prev.pitch[L - 1]));
-        }
+        // next level's template loads fly while this level iterates (issued once the search tile is committed, see above)
+        auto issue_next_template = [&]() {
+            if (L > 0) {
+                const float sn = 1.0f / (float)(1u << (L - 1));
+                p_x0 = (int)floorf(px * sn) - half - 1;
+                const int p_y0 = (int)floorf(py * sn) - half - 1;
+                const int nw = (int)a.prev.width[L - 1];
+                tile_issue<NLP, NDP>(tp, lane, a.prev.ptr[L - 1], a.prev.pitch[L - 1], nw, (int)a.prev.height[L - 1], p_x0, p_y0,
+                           ALIGNED && tile_inside(p_x0, PW, NDP, nw, a.prev.pitch[L - 1]));
+            }
+        };
 
         const float det = Gxx * Gyy - Gxy * Gxy;
         const float dxy = Gxx - Gyy;
@@ -425,6 +437,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         if (!(min_eig >= 1e-4f) || !(det >= FLT_EPSILON)) {
             if (L == 0) ok = false;
             gx = 2.0f * gx; gy = 2.0f * gy;
+            issue_next_template();
             continue;
         }
         const float inv_det = 1.0f / det;
@@ -433,6 +446,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         __syncthreads();   // every lane is done with P
         tile_commit<NLJ, NDJ, JS4>(tj, lane, J);
         __syncthreads();
+        issue_next_template();
         LK_PHASE(2);
 
         float ja[NSEG + 1], jb[NSEG + 1];                     // search rows jy + row and jy + row + 1 at columns jx + x0 ..
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 // drain (-9 % on the 32-stream bench at 109 registers).  On gfx950 the attribute counts the unified VGPR + AGPR file in
 // halves: 52 caps the kernel at 104.
 template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(52))) void k_pyrlk_104(LKArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(VSA_LK_VGPR_HALF))) void k_pyrlk_104(LKArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a, blockIdx.x, smem);
@@ -600,7 +614,7 @@ __global__ __launch_bounds__(64) void k_pyrlk_cells(LKArgs a, CornerArgs c)
     pyrlk_cells_wave<NSEG, WMAX, FULL>(a, c);
 }
 template <int NSEG, int WMAX, bool FULL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(52))) void k_pyrlk_cells_104(LKArgs a, CornerArgs c)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(VSA_LK_VGPR_HALF))) void k_pyrlk_cells_104(LKArgs a, CornerArgs c)
 {
     pyrlk_cells_wave<NSEG, WMAX, FULL>(a, c);
 }
