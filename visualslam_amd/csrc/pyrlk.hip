@@ -165,6 +165,8 @@ struct TileRegs {
 // number, so that the compiler cannot hoist them back out of the level loop: the registers go to the iteration loop's
 // cache of search rows instead, and the kernel stays at 4 waves per SIMD with room for other kernels' waves.
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// 1 / 2^l, exactly (what 1.0f / (float)(1u << l) rounds to, without the division's dozen instructions)
+__device__ __forceinline__ float pow2_recip(int l) { return __uint_as_float((uint32_t)(127 - l) << 23); }
 
 // fast: the tile's dwords lie inside the row allocation and inside the image columns, and the level is
 // 4-byte aligned -> one dword load per slot.  Otherwise four clamped byte loads (replicate border).
@@ -298,13 +300,25 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
     auto lane_base_t = [&]() { return (FULL && idle) ? TILE_FLOATS + PS + NSEG + 8 - TBASE : opaque(row) * TS + x0; };   // T rows behind the strip's template part
     static_assert(PS + NSEG + 8 + 2 * TS + NSEG + 2 <= ZSTRIP, "zero strip holds an idle lane's template and T accesses");
 
+    // the top level's template tile first: nothing hides its loads but the set-up below
+    const int top = (int)a.prev.levels - 1;
+    const float s_top = pow2_recip(top);
+    TileRegs<NLP> tp;
+    TileRegs<NLJ> tj;
+    int p_x0 = 0;
+    if (ok) {
+        p_x0 = (int)floorf(px * s_top) - half - 1;
+        const int p_y0 = (int)floorf(py * s_top) - half - 1;
+        const int tw = (int)a.prev.width[top];
+        tile_issue<NLP, NDP>(tp, lane, a.prev.ptr[top], a.prev.pitch[top], tw, (int)a.prev.height[top], p_x0, p_y0,
+                   ALIGNED && tile_inside(p_x0, PW, NDP, tw, a.prev.pitch[top]));
+    }
+
     // LDS only ever holds converted pixels, resampled template values or the zeros written here (the slack a lane may
     // over-read past its segment at the end of either tile region, T entries nobody computes), so idle pixels
     // multiply finite values by exact zeros
     for (int i = PFLOATS + lane; i < LDS_FLOATS; i += 64) smem[i] = 0.0f;
 
-    const int top = (int)a.prev.levels - 1;
-    const float s_top = 1.0f / (float)(1u << top);
     float gx = (ex - px) * s_top, gy = (ey - py) * s_top;
     float vx = 0.0f, vy = 0.0f;
     // wave-uniform and needed once per level: held in a scalar register, not in one of the 104 vector registers
@@ -319,22 +333,11 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
     float Iw[NSEG], Ix[NSEG], Iy[NSEG];
     float err = 0.0f;
 
-    TileRegs<NLP> tp;
-    TileRegs<NLJ> tj;
-    int p_x0 = 0;
-    if (ok) {   // template tile of the top level
-        p_x0 = (int)floorf(px * s_top) - half - 1;
-        const int p_y0 = (int)floorf(py * s_top) - half - 1;
-        const int tw = (int)a.prev.width[top];
-        tile_issue<NLP, NDP>(tp, lane, a.prev.ptr[top], a.prev.pitch[top], tw, (int)a.prev.height[top], p_x0, p_y0,
-                   ALIGNED && tile_inside(p_x0, PW, NDP, tw, a.prev.pitch[top]));
-    }
-
     for (int L = top; L >= 0 && ok; --L) {
         const int lw = (int)a.prev.width[L], lh = (int)a.prev.height[L];
         const uint8_t *jp = a.curr.ptr[L];
         const uint32_t jpitch = a.curr.pitch[L];
-        const float s = 1.0f / (float)(1u << L);
+        const float s = pow2_recip(L);
         const float ux = px * s, uy = py * s;
         const float ax = ux - floorf(ux), ay = uy - floorf(uy);
         vx = 0.0f; vy = 0.0f;
@@ -421,7 +424,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         // next level's template loads fly while this level iterates (issued once the search tile is committed, see above)
         auto issue_next_template = [&]() {
             if (L > 0) {
-                const float sn = 1.0f / (float)(1u << (L - 1));
+                const float sn = pow2_recip(L - 1);
                 p_x0 = (int)floorf(px * sn) - half - 1;
                 const int p_y0 = (int)floorf(py * sn) - half - 1;
                 const int nw = (int)a.prev.width[L - 1];
@@ -586,9 +589,14 @@ __global__ __launch_bounds__(64) void k_pyrlk(LKArgs a)
 // SIMD's 512 registers to other camera streams' detector (92) and merge (48) waves, which otherwise wait for PyrLK waves to
 // drain (-9 % on the 32-stream bench at 109 registers).  On gfx950 the attribute counts the unified VGPR + AGPR file in
 // halves: 52 caps the kernel at 104.
+// ... and with no fewer: at 96 registers or less a fifth wave fits on a SIMD, and a GPU full of PyrLK waves keeps the other
+// camera streams' short kernels waiting (-9 % on the bench at 92 registers, -15 % at 96 with spills).  Naming v103 in an
+// empty asm statement makes the allocation 104 whatever the compiler needs.
+#define VSA_LK_PIN_104() asm volatile("" ::: "v103")
 template <int NSEG, int WMAX, bool ALIGNED, bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(VSA_LK_VGPR_HALF))) void k_pyrlk_104(LKArgs a)
 {
+    VSA_LK_PIN_104();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a, blockIdx.x, smem);
 }
@@ -616,6 +624,7 @@ __global__ __launch_bounds__(64) void k_pyrlk_cells(LKArgs a, CornerArgs c)
 template <int NSEG, int WMAX, bool FULL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(VSA_LK_VGPR_HALF))) void k_pyrlk_cells_104(LKArgs a, CornerArgs c)
 {
+    VSA_LK_PIN_104();
     pyrlk_cells_wave<NSEG, WMAX, FULL>(a, c);
 }
 
