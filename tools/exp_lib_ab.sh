@@ -1,10 +1,10 @@
-# A/B of library builds on the default bench: alternating runs of the in-tree library and the variants named on the command line
+# A/B of library builds on the default bench (or on BENCH_ARGS, e.g. BENCH_ARGS="--config c3 --steps 300"): alternating runs of the in-tree library and the variants named on the command line
 # (paths relative to the repository root), three repetitions each; then the single-stream rate and isolated PyrLK launch time of each.
 # A variant is copied to a directory of its own under the in-tree name, with the native driver library beside it (the driver
 # binds libvisualslam_amd.so from its own directory).
 set -e
 cd $GRAFT_REPO_ROOT
-one() { timeout -k 10 120 python bench.py --no-cpu-baseline "$@" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["roofline"]["launch_ms"]*1000,1))'; }
+one() { timeout -k 10 200 python bench.py --no-cpu-baseline $BENCH_ARGS "$@" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"]), round(d["roofline"]["launch_ms"]*1000,1))'; }
 i=0
 for v in "$@"; do
   i=$((i+1)); d=/tmp/vsa_variant_$i; mkdir -p $d
