@@ -237,6 +237,9 @@ def main():
     local_device = rank_device(local_rank, torch.cuda.device_count())
     torch.cuda.set_device(local_device)
     os.environ["VISUALSLAM_AMD_DEVICE"] = str(local_device)     # vxCreateContext binds this rank's GPU explicitly
+    # the camera streams' graphs get HIP streams of greatest priority: a pool of hardware queues of their own, on which HIP deals
+    # them out evenly; nothing else runs on this GPU during the timed region
+    os.environ.setdefault("VISUALSLAM_AMD_STREAM_PRIORITY", "-1")
     device = f"cuda:{local_device}"
     nvxcu.lib()
 
@@ -417,7 +420,8 @@ def main():
                                                       if args.homography else ""),
                        "baseline_config": 4 if args.homography else cfg["baseline_config"], "frames": cfg["frames"],
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
-                       "frame_ring": args.ring, "api": api_desc},
+                       "frame_ring": args.ring, "api": api_desc,
+                       "graph_stream_priority": int(os.environ["VISUALSLAM_AMD_STREAM_PRIORITY"]) if args.api == "ovx" else None},
             "per_rank_frames_per_s": rank_fps,
             "tracks_per_sec": fps * float(np.mean(n_tracks)),
             "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),

@@ -494,3 +494,17 @@ def test_cell_pass_is_not_fused_when_its_image_is_written_after_pyrlk_starts(ctx
     w, h = 320, 240
     p = Params(pyr_levels=3, lk_win_size=21, use_harris_detector=True, harris_thresh=2000.0, array_capacity=600)
     _run_sequence(ctx, p, w, h, _frames(w, h, 4, seed=77), detect_on_copy=True)
+
+
+@pytest.mark.parametrize("prio", ["-1", "1"])
+def test_graph_streams_created_with_a_priority(gpu, monkeypatch, prio):
+    """VISUALSLAM_AMD_STREAM_PRIORITY gives the graphs' HIP streams a priority (a hardware-queue pool of their own): same results"""
+    monkeypatch.setenv("VISUALSLAM_AMD_STREAM_PRIORITY", prio)
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    try:
+        w, h = 320, 240
+        p = Params(pyr_levels=3, lk_win_size=21, use_harris_detector=True, harris_thresh=2000.0, array_capacity=500)
+        _run_sequence(c, p, w, h, _frames(w, h, 3, seed=5))
+    finally:
+        assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS

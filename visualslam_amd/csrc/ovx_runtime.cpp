@@ -1197,7 +1197,18 @@ vx_status verify_graph(_vx_graph *g)
                 return VX_ERROR_NO_MEMORY;
             g->pinned_slots = slots;
         }
-        if (!g->stream && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) return VX_FAILURE;
+        if (!g->stream) {
+            // VISUALSLAM_AMD_STREAM_PRIORITY=<p> (-1 greatest, 1 least; unset = normal) creates the graphs' streams with that
+            // priority.  HIP keeps a pool of hardware queues per priority and deals a pool's streams round-robin over its queues:
+            // at normal priority the graphs share the pool with the process's other streams (32 camera streams landed 9/7/7/9 on
+            // the four queues), with a priority of their own they get 8/8/8/8 -- +2.8 % on the 32-stream bench, the same for -1
+            // and 1 (tools/queue_probe.hip, profiles/r02_kernel_experiments.txt).  Opt-in: a priority also ranks the graphs'
+            // kernels against the application's other GPU work.
+            const char *e = getenv("VISUALSLAM_AMD_STREAM_PRIORITY");
+            const hipError_t err = e ? hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, atoi(e))
+                                     : hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+            if (err != hipSuccess) return VX_FAILURE;
+        }
     }
     g->verified = true;
     g->state = VX_GRAPH_STATE_VERIFIED;
