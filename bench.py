@@ -421,7 +421,7 @@ def main():
                        "baseline_config": 4 if args.homography else cfg["baseline_config"], "frames": cfg["frames"],
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
                        "frame_ring": args.ring, "api": api_desc,
-                       "graph_stream_priority": int(os.environ["VISUALSLAM_AMD_STREAM_PRIORITY"]) if args.api == "ovx" else None},
+                       "graph_stream_priority": os.environ["VISUALSLAM_AMD_STREAM_PRIORITY"] if args.api == "ovx" else None},
             "per_rank_frames_per_s": rank_fps,
             "tracks_per_sec": fps * float(np.mean(n_tracks)),
             "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),
