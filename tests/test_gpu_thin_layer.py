@@ -446,3 +446,43 @@ def test_cpp_thin_layer_application(gpu, tmp_path, detector, noalloc, use_mask):
             assert cnt == len(want) and cnt > 100
             assert got.tobytes() == want.tobytes(), f"frame {t}"
     assert off == raw.size
+
+
+# --------------------------------------------------------------------------- the reference's object tracker on the thin layer
+@pytest.mark.parametrize("detector", ["fast", "harris"])
+def test_reference_object_tracker_on_the_thin_layer(gpu, tmp_path, detector):
+    """oracle/_ref/ot_headless: samples/object_tracker_nvxcu/{object_tracker_keypoint,object_tracker,
+    object_tracker_with_features_info}_nvxcu.cpp compiled where they lie (runtime calls renamed cuda* -> hip*, INTEGRATION.md
+    section 2) against include/NVX/nvxcu.h and linked with libvisualslam_amd: nvxcuGaussianPyramid (REPLICATE border),
+    nvxcuFastTrack / nvxcuHarrisTrack into KEYPOINTF arrays with a mask, and the forward-backward nvxcuOpticalFlowPyrLK pair
+    of object_tracker_keypoint_nvxcu.cpp:1748-1840, whose tracking_status == 255 / strength contract (:1887, :1912) decides
+    which points move the box.  The reference holds no expected output for this sample (parity unpinned), so the check is
+    the ground truth of the synthetic sequence: a textured object gliding over a textured background must stay TRACKED and
+    its box must follow it."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "ot_headless")
+    assert os.path.exists(exe), "oracle/_ref/ot_headless is missing: built by oracle/Makefile.ref"
+    w, h, n = 640, 480, 12
+    bg = synth.gray_frame(synth.base_frame(w, h, 5), 0)
+    ob = synth.gray_frame(synth.base_frame(w, h, 6), 0)[100:220, 200:360]          # 160 x 120 patch of other texture
+    x0, y0, vx, vy = 180, 150, 3, 2
+    with open(tmp_path / "frames.u8", "wb") as f:
+        for t in range(n):
+            fr = bg.copy()
+            fr[y0 + vy * t:y0 + vy * t + 120, x0 + vx * t:x0 + vx * t + 160] = ob
+            f.write(fr.tobytes())
+    cmd = [exe, str(tmp_path / "frames.u8"), str(w), str(h), str(n), str(x0), str(y0), str(x0 + 160), str(y0 + 120),
+           f"detector={detector}", "harris_threshold=100", "fast_threshold=25"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = [l.split() for l in res.stdout.splitlines() if l.startswith("frame ")]
+    assert len(lines) == n - 1, res.stdout + res.stderr
+    for l in lines:
+        t, status = int(l[1]), int(l[3])
+        bx0, by0, bx1, by1 = (int(v) for v in l[4:8])
+        assert status == 0, res.stdout                                           # ObjectTracker::TRACKED
+        cx, cy = 0.5 * (bx0 + bx1), 0.5 * (by0 + by1)
+        assert abs(cx - (x0 + vx * t + 80)) <= 6 and abs(cy - (y0 + vy * t + 60)) <= 6, res.stdout
+        assert abs((bx1 - bx0) - 160) <= 16 and abs((by1 - by0) - 120) <= 16, res.stdout
