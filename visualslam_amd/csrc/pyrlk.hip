@@ -452,7 +452,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         issue_next_template();
         LK_PHASE(2);
 
-        float ja[NSEG + 1], jb[NSEG + 1];                     // search rows jy + row and jy + row + 1 at columns jx + x0 ..
+        float ja[NSEG + 1], jd[NSEG + 1];                     // search row jy + row at columns jx + x0 .. and row jy + row + 1 MINUS it
         int cached_jx = INT_MIN, cached_jy = INT_MIN;         // ... for this integer position (none yet at this level)
         for (uint32_t it = 0; it < a.max_it; ++it) {
             const float cx = (ux + gx) + vx, cy = (uy + gy) + vy;
@@ -479,19 +479,21 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
             // The two search-tile rows a lane samples depend only on the INTEGER part of the position.  After a level's first
             // iteration the update is usually a fraction of a pixel, so the rows are kept in registers and re-read only when
             // the integer position moves: the iteration loop is bound by the LDS pipe (16 dword reads per lane with 2-way
-            // bank conflicts; profiles/r02_kernel_experiments.txt), and most iterations now read nothing.
+            // bank conflicts; profiles/r02_kernel_experiments.txt), and most iterations now read nothing.  What is kept of the
+            // lower row is its difference from the upper one (exact: both are integers below 256), the only form the vertical
+            // lerp uses: eight subtractions less in every iteration that reads nothing.
             if (jx != cached_jx || jy != cached_jy) {   // wave-uniform
                 const float *jt = J + lane_base_j() + (oy * JS + (jx0 & 3) + ox);
 #pragma unroll
-                for (int k = 0; k < NSEG + 1; ++k) { ja[k] = jt[k]; jb[k] = jt[JS + k]; }
+                for (int k = 0; k < NSEG + 1; ++k) { ja[k] = jt[k]; jd[k] = jt[JS + k] - ja[k]; }
                 cached_jx = jx; cached_jy = jy;
             }
             float b1 = 0.0f, b2 = 0.0f;
             {
-                float cp = fmaf(by, jb[0] - ja[0], ja[0]);
+                float cp = fmaf(by, jd[0], ja[0]);
 #pragma unroll
                 for (int k = 0; k < NSEG; ++k) {   // pixels past cnt have Ix = Iy = 0 and add exact zeros
-                    const float cc = fmaf(by, jb[k + 1] - ja[k + 1], ja[k + 1]);
+                    const float cc = fmaf(by, jd[k + 1], ja[k + 1]);
                     const float jv = fmaf(bx, cc - cp, cp);
                     const float d = Iw[k] - jv;
                     b1 = fmaf(d, Ix[k], b1);
