@@ -38,11 +38,13 @@ assert rc == 0, rc
 s = buf.reshape(n, 8)
 t0, t1 = s[:, 0].astype(np.int64), s[:, 1].astype(np.int64)
 hw, xcc = (s[:, 2] & 0xffffffff).astype(np.int64), (s[:, 2] >> 32).astype(np.int64) & 0xf
-wall, iters = (s[:, 3] >> 32).astype(np.int64), (s[:, 3] & 0xffffffff).astype(np.int64)
+wall, iters = (s[:, 3] >> 32).astype(np.int64), (s[:, 3] & 0xff).astype(np.int64)
+first_head = ((s[:, 3] >> 8) & 0xffffff).astype(np.int64)
 life = t1 - t0
 ph = s[:, 4:8].astype(np.int64)
 print("phase cycles per wave (mean): level head + P commit %.0f, template pass %.0f, solve + J commit %.0f, iterations %.0f (%.0f per iteration); outside %.0f"
-      % (*ph.mean(axis=0), ph[:, 3].sum() / max(1, s[:, 3].astype(np.int64).__and__(0xffffffff).sum()), (t1 - t0 - ph.sum(axis=1)).mean()))
+      % (*ph.mean(axis=0), ph[:, 3].sum() / max(1, iters.sum()), (t1 - t0 - ph.sum(axis=1)).mean()))
+print("wave start .. top level's template tile in LDS (cycles): mean %.0f p10 %.0f p50 %.0f p90 %.0f" % (first_head.mean(), *np.percentile(first_head, [10, 50, 90])))
 print("waves", n, "iters/wave mean %.2f min %d max %d" % (iters.mean(), iters.min(), iters.max()))
 print("lifetime cycles: mean %.0f  p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % (life.mean(), *np.percentile(life, [10, 50, 90]), life.max()))
 print("wall ticks (100 MHz) per wave: mean %.1f  max %d  -> shader clock ~ %.0f MHz" % (wall.mean(), wall.max(), life.mean() / wall.mean() * 100))

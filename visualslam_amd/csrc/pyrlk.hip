@@ -245,7 +245,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
 #ifdef VSA_LK_STAMPS
     const uint64_t st_t0 = __builtin_readcyclecounter();
     const uint64_t st_w0 = wall_clock64();
-    uint32_t st_iters = 0;
+    uint32_t st_iters = 0, st_first_head = 0;
     uint64_t st_ph[4] = {0, 0, 0, 0};   // cycles in: level head + P commit, template pass, solve + J commit, iterations
 #define LK_PHASE(i) do { const uint64_t now_ = __builtin_readcyclecounter(); st_ph[i] += now_ - st_mark; st_mark = now_; } while (0)
     uint64_t st_mark = st_t0;
@@ -358,6 +358,9 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         tile_commit<NLP, NDP, PS4>(tp, lane, P);
         __syncthreads();
         LK_PHASE(0);
+#ifdef VSA_LK_STAMPS
+        if (L == top) st_first_head = (uint32_t)(st_mark - st_t0);   // wave start .. top level's template tile in LDS
+#endif
 
         // Template pass.  T(R, C), R, C = 0 .. win+1, is the template resampled at the feature's sub-pixel offset on the window
         // plus a one-pixel ring: v(R, c) = lerp_y(P(R, c), P(R+1, c)), T(R, C) = lerp_x(v(R, C), v(R, C+1)).  A lane needs three
@@ -575,7 +578,7 @@ __device__ __forceinline__ void pyrlk_wave(const LKArgs &a, const uint32_t bid, 
         const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         uint64_t *o = g_lk_stamps + 8 * bid;
         o[0] = st_t0; o[1] = __builtin_readcyclecounter(); o[2] = ((uint64_t)xcc << 32) | hw;
-        o[3] = ((wall_clock64() - st_w0) << 32) | st_iters;
+        o[3] = ((wall_clock64() - st_w0) << 32) | (st_iters & 0xffu) | (min(st_first_head, 0xffffffu) << 8);
         o[4] = st_ph[0]; o[5] = st_ph[1]; o[6] = st_ph[2]; o[7] = st_ph[3];
     }
 #endif
