@@ -32,7 +32,8 @@ constexpr int PXS = (PXW + 3 + 3) / 4 * 4;   // LDS row stride of the staged pix
 constexpr int SW = TW + 2, SH = TH + 2; // score grid     (interior + 1)
 constexpr uint64_t OCCUPIED = ~0ull;
 
-// i / d for 0 <= i < 4096 and 1 <= d <= 128 through m = fast_div_magic(d): (i * m) >> 22 (m * d - 2^22 <= d and i * d < 2^22)
+// i / d for 1 <= d <= 128 and 0 <= i < 64 d (rows of d items, at most 64 rows) through m = fast_div_magic(d): (i * m) >> 22
+// (m * d - 2^22 <= d and i * d < 2^22; i * m < 2^32; tests/test_abi.py checks every case)
 __device__ __forceinline__ uint32_t fast_div_magic(uint32_t d) { return (1u << 22) / d + 1u; }
 __device__ __forceinline__ uint32_t fast_div(uint32_t i, uint32_t m) { return (i * m) >> 22; }
 
