@@ -80,9 +80,9 @@ def test_gaussian_pyramid_rejects_wrong_level_size(gpu):
 
 
 # --------------------------------------------------------------------------- Harris / FAST track
-def _run_track(kind, gray, mask, tracked, item_type, cell, capacity, **kw):
+def _run_track(kind, gray, mask, tracked, item_type, cell, capacity, pitch=None, **kw):
     h, w = gray.shape
-    img = DeviceImage(w, h).upload(gray)
+    img = DeviceImage(w, h, pitch=pitch).upload(gray)
     out = DeviceArray(capacity, item_type)
     mimg = DeviceImage(w, h).upload(mask) if mask is not None else None
     tarr = None
@@ -199,6 +199,25 @@ def test_fast_track(gpu, w, h, cell, cap, n, thr):
     want, wtot, _ = O.fast_track(gray, mask, None, n, thr, cell, cap, item_type=O.KEYPOINTF)
     assert gtot == wtot and len(got) == len(want)
     assert wtot > 0
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("w,h,cell,n,thr,pitch", [
+    (109, 73, 18, 9, 20, None),      # the last rectangle of cells is one pixel wide and one pixel high
+    (163, 38, 18, 10, 20, None),     # ... and two rows high
+    (131, 97, 130, 9, 15, None),     # a cell larger than a tile: tiles of 64, 64 and 2 columns, 40, 40 and 17 rows
+    (200, 150, 65, 12, 10, None),
+    (257, 131, 18, 9, 20, 259),      # rows not 4-byte aligned: the byte path of the staging
+    (66, 45, 64, 11, 10, 67),
+    (7, 7, 18, 9, 5, None), (6, 9, 2, 9, 5, None)])   # too small for a circle / barely large enough
+def test_fast_track_tile_shapes(gpu, w, h, cell, n, thr, pitch):
+    """k_fast_cells walks every tile over exactly its own items (rows and columns from a multiply and a shift) and stages
+    it as aligned dwords when the image allows: the shapes the tiles take at image edges, with cells larger than a tile and
+    with unaligned rows must give the oracle's corners, bit for bit."""
+    gray = _scene(w, h, seed=3 * w + h + n)
+    got, gtot = _run_track("fast", gray, None, None, nvxcu.NVXCU_TYPE_KEYPOINTF, cell, 5000, pitch=pitch, type_n=n, threshold=thr)
+    want, wtot, _ = O.fast_track(gray, None, None, n, thr, cell, 5000, item_type=O.KEYPOINTF)
+    assert gtot == wtot and len(got) == len(want)
     assert got.tobytes() == want.tobytes()
 
 
