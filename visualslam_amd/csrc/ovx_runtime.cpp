@@ -1487,6 +1487,11 @@ vx_context vxCreateContext(void)
         const int want = atoi(dev);
         if (want < 0 || want >= count || hipSetDevice(want) != hipSuccess) { ctx->status = VX_ERROR_INVALID_PARAMETERS; return ctx; }
     }
+    // VISUALSLAM_AMD_BLOCKING_SYNC=1: the host waits for a graph asleep (hipDeviceScheduleBlockingSync) instead of polling.
+    // HIP's default keeps a core busy per waiting thread; an application with more camera-stream threads than cores then
+    // has threads waiting milliseconds for a core while others poll.  Process-wide, so opt-in.
+    if (const char *b = getenv("VISUALSLAM_AMD_BLOCKING_SYNC"))
+        if (b[0] == '1') (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     if (hipGetDevice(&ctx->device) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&ctx->pinned), 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {

@@ -12,7 +12,10 @@
 #include <VX/vx.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -69,9 +72,14 @@ struct vsa_driver {
     std::vector<std::thread> threads;
     std::mutex mu;
     std::condition_variable go, done;
-    unsigned long generation = 0;     // bumped by every run (and by destroy)
+    std::atomic<unsigned long> generation{0};     // bumped by every run (and by destroy)
     int k0 = 0, n_frames = 0, running = 0, first_error = VX_SUCCESS;
     bool quit = false;
+    // VSA_DRIVER_TRACE=<prefix>: the time every frame of a run completed on the host (microseconds from the run's start),
+    // one line per stream, into <prefix>.<streams>_streams_<frames>_frames -- where a short run loses its time (tools/exp_trace_run.sh)
+    const char *trace_path = nullptr;
+    std::vector<double> trace, trace_start;   // trace_start: when the stream's thread began the run
+    std::chrono::steady_clock::time_point t_run;
 };
 
 static void vsa_driver_thread(vsa_driver *d, int i)
@@ -81,13 +89,24 @@ static void vsa_driver_thread(vsa_driver *d, int i)
         int k0, n;
         {
             std::unique_lock<std::mutex> lk(d->mu);
-            d->go.wait(lk, [&] { return d->generation != seen; });
-            seen = d->generation;
+            d->go.wait(lk, [&] { return d->generation.load(std::memory_order_acquire) != seen; });
+            seen = d->generation.load(std::memory_order_acquire);
             if (d->quit) return;
             k0 = d->k0; n = d->n_frames;
         }
-        const int s = vsa_drive_stream(d->graphs[i], d->cvt[i], d->det[i], d->pyr_delay[i], d->pts_delay[i], d->ring.data(),
-                                       (int)d->ring.size(), d->phase[i], k0, n);
+        int s = VX_SUCCESS;
+        if (!d->trace_path) {
+            s = vsa_drive_stream(d->graphs[i], d->cvt[i], d->det[i], d->pyr_delay[i], d->pts_delay[i], d->ring.data(),
+                                 (int)d->ring.size(), d->phase[i], k0, n);
+        } else {
+            d->trace_start[(size_t)i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - d->t_run).count();
+            for (int j = 0; j < n && s == VX_SUCCESS; ++j) {
+                s = vsa_drive_stream(d->graphs[i], d->cvt[i], d->det[i], d->pyr_delay[i], d->pts_delay[i], d->ring.data(),
+                                     (int)d->ring.size(), d->phase[i], k0 + j, 1);
+                d->trace[(size_t)i * (size_t)n + (size_t)j] =
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - d->t_run).count();
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(d->mu);
             if (s != VX_SUCCESS && d->first_error == VX_SUCCESS) d->first_error = s;
@@ -108,6 +127,7 @@ vsa_driver *vsa_driver_create(int n_streams, const vx_graph *graphs, const vx_no
     d->pts_delay.assign(pts_delay, pts_delay + n_streams);
     d->ring.assign(ring, ring + ring_len);
     d->phase.assign(phase, phase + n_streams);
+    d->trace_path = getenv("VSA_DRIVER_TRACE");
     for (int i = 0; i < n_streams; ++i) d->threads.emplace_back(vsa_driver_thread, d, i);
     return d;
 }
@@ -120,9 +140,22 @@ int vsa_driver_run(vsa_driver *d, int k0, int n_frames)
     d->k0 = k0; d->n_frames = n_frames;
     d->running = (int)d->threads.size();
     d->first_error = VX_SUCCESS;
-    ++d->generation;
+    if (d->trace_path) { d->trace_start.assign(d->threads.size(), 0.0); d->trace.assign(d->threads.size() * (size_t)n_frames, 0.0); d->t_run = std::chrono::steady_clock::now(); }
+    d->generation.fetch_add(1, std::memory_order_release);   // k0 / n_frames / running are published with it
     d->go.notify_all();
     d->done.wait(lk, [&] { return d->running == 0; });
+    if (d->trace_path) {
+        char path[1024];
+        snprintf(path, sizeof(path), "%s.%zu_streams_%d_frames", d->trace_path, d->threads.size(), n_frames);
+        if (FILE *f = fopen(path, "w")) {   // one file per (stream count, run length): a later run of the same shape replaces it
+            for (size_t i = 0; i < d->threads.size(); ++i) {
+                fprintf(f, "%.1f ", d->trace_start[i]);   // first column: the thread's start
+                for (int j = 0; j < n_frames; ++j) fprintf(f, "%.1f ", d->trace[i * (size_t)n_frames + (size_t)j]);
+                fputc('\n', f);
+            }
+            fclose(f);
+        }
+    }
     return d->first_error;
 }
 
@@ -132,7 +165,7 @@ void vsa_driver_destroy(vsa_driver *d)
     {
         std::lock_guard<std::mutex> lk(d->mu);
         d->quit = true;
-        ++d->generation;
+        d->generation.fetch_add(1, std::memory_order_release);
     }
     d->go.notify_all();
     for (auto &t : d->threads) t.join();
