@@ -140,7 +140,8 @@ int vsa_driver_run(vsa_driver *d, int k0, int n_frames)
     d->k0 = k0; d->n_frames = n_frames;
     d->running = (int)d->threads.size();
     d->first_error = VX_SUCCESS;
-    if (d->trace_path) { d->trace_start.assign(d->threads.size(), 0.0); d->trace.assign(d->threads.size() * (size_t)n_frames, 0.0); d->t_run = std::chrono::steady_clock::now(); }
+    if (d->trace_path) { d->trace_start.assign(d->threads.size(), 0.0); d->trace.assign(d->threads.size() * (size_t)n_frames, 0.0); }
+    d->t_run = std::chrono::steady_clock::now();
     d->generation.fetch_add(1, std::memory_order_release);   // k0 / n_frames / running are published with it
     d->go.notify_all();
     d->done.wait(lk, [&] { return d->running == 0; });
