@@ -701,6 +701,7 @@ hipError_t launch_lk(const PyrLKParams &p, hipStream_t stream, const CornerArgs 
     a.segs = (win + a.seglen - 1) / a.seglen;
     a.lanes = a.segs * win;
 
+    if (win <= 8) return launch_bucket<1, 8>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);   // one pixel per lane
     if (win <= 10) return launch_bucket<2, 10>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
     if (win <= 16) return launch_bucket<4, 16>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
     if (win <= 21) return launch_bucket<7, 21>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
