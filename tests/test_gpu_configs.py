@@ -231,3 +231,17 @@ def test_homography_node_first_run_with_poisoned_memory(ctx):
             ovx.check(L.vxCopyMatrix(m, out.ctypes.data, ovx.VX_READ_ONLY, ovx.VX_MEMORY_TYPE_HOST))
             assert out.tobytes() == Hw.tobytes(), f"run {run}"
             assert ovx.read_array(mask, np.uint8).tobytes() == mw.tobytes(), f"run {run}"
+
+
+def test_blocking_sync_option_runs_the_same_frames(gpu):
+    """VISUALSLAM_AMD_BLOCKING_SYNC=1 (vxCreateContext sets hipDeviceScheduleBlockingSync: the host waits for a graph asleep
+    instead of polling) changes how the host waits, not what the graph computes: tools/soak.py --
+    the headline workload through one graph against the oracle's frame loop, every frame byte for byte -- in a process of its
+    own, because the flag is process-wide."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VISUALSLAM_AMD_BLOCKING_SYNC="1")
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "6"], env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0 and "SOAK_OK 6 frames identical to the oracle" in res.stdout, res.stdout[-600:] + res.stderr[-600:]
