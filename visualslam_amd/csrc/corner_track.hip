@@ -173,19 +173,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(CornerArgs a)
                 const uint32_t m = fast_div_magic((uint32_t)tw);
                 for (int i0 = 0; i0 < tw * th; i0 += 256) {   // every wave takes part in every ballot
                     const int i = i0 + tid;
-                    bool cand = false;
-                    float s = 0.0f;
-                    int lx = 0, ly = 0;
-                    if (i < tw * th) {
-                        ly = (int)fast_div((uint32_t)i, m); lx = i - ly * tw;
-                        const float *q = sc + (ly + 1) * gw + (lx + 1);
-                        s = q[0];
-                        cand = (s >= a.thr) && (s != -INFINITY);
-                        if (cand) {
-                            cand = !(q[-gw - 1] >= s) && !(q[-gw] >= s) && !(q[-gw + 1] >= s) && !(q[-1] >= s) &&
-                                   !(q[1] > s) && !(q[gw - 1] > s) && !(q[gw] > s) && !(q[gw + 1] > s);
-                        }
-                    }
+                    // all nine scores are read unconditionally (from a clamped item for the lanes past the tile's end) and combined
+                    // without short circuits: as a chain of && every neighbour was a branch with an LDS round trip of its own
+                    const int ic = min(i, tw * th - 1);
+                    const int ly = (int)fast_div((uint32_t)ic, m), lx = ic - ly * tw;
+                    const float *q = sc + (ly + 1) * gw + (lx + 1);
+                    const float s = q[0];
+                    const float n0 = q[-gw - 1], n1 = q[-gw], n2 = q[-gw + 1], n3 = q[-1], n4 = q[1], n5 = q[gw - 1], n6 = q[gw], n7 = q[gw + 1];
+                    const bool cand = (i < tw * th) & (s >= a.thr) & (s != -INFINITY) &
+                                      !(n0 >= s) & !(n1 >= s) & !(n2 >= s) & !(n3 >= s) & !(n4 > s) & !(n5 > s) & !(n6 > s) & !(n7 > s);
                     if (__ballot(cand) == 0ull) continue;  // wave-uniform early out: candidates are sparse
                     if (cand) {
                         const int gx = gx0 + lx, gy = gy0 + ly;
