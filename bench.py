@@ -36,20 +36,41 @@ CONFIGS = {
                workload="640x480 frames, 6-level pyramid, <=2000 Harris features (cell 18, k 0.04, threshold 2000), 6x6 PyrLK window, "
                         "5 iters (data/feature_tracker_demo_config.ini)",
                bytes=dict(pyramid=409200 + 102300, detect=307200 + 16000, lk=819000 + 32000, cvt=1536000),
-               lk_kernel="k_pyrlk<2,10,true,false>", lk_cells_kernel="k_pyrlk_cells<2,10,false>"),
+               ),
     "c2": dict(baseline_config=1, width=1920, height=1080, levels=5, capacity=4096, cell=18, win=21, iters=5,
                harris=True, harris_thresh=100.0, ring=64, streams=32,
                frames="1080p synthetic RGBX frames (seed 1234: low-pass noise + blobs, known sub-pixel drift, per-frame noise)",
                workload="1080p synthetic RGBX frames, 5-level pyramid, 4k Harris features (cell 18), 21x21 PyrLK window, 5 iters",
                bytes=dict(pyramid=2754000 + 688560, detect=2073600 + 32768, lk=5524320 + 65536, cvt=10368000),
-               lk_kernel="k_pyrlk_104<7,21,true,true>", lk_cells_kernel="k_pyrlk_cells_104<7,21,true>"),
+               ),
     "c3": dict(baseline_config=2, width=3840, height=2160, levels=7, capacity=10000, cell=18, win=21, iters=5,
                harris=False, harris_thresh=100.0, ring=16, streams=16,
                frames="4K synthetic RGBX frames (seed 1234: low-pass noise + blobs, known sub-pixel drift, per-frame noise)",
                workload="4K synthetic RGBX frames, 7-level pyramid, FAST-9 (threshold 25) track with 10k features (cell 18), 21x21 PyrLK window, 5 iters",
                bytes=dict(pyramid=11056560 + 2764200, detect=8294400 + 80000, lk=22117200 + 160000, cvt=41472000),
-               lk_kernel="k_pyrlk_104<7,21,true,true>", lk_cells_kernel=None),
+               ),
 }
+
+
+def lk_kernel_names(win):
+    """(PyrLK alone, PyrLK + detector cell pass): the instantiations pyrlk.hip's launch_lk / launch_bucket pick for this window on
+    4-byte-aligned pyramids -- the same bucket and lane-map arithmetic, so the bench line names the kernel that ran"""
+    segs = max(1, min(64 // win, win))
+    seglen = (win + segs - 1) // segs
+    segs = (win + seglen - 1) // seglen
+    nseg, wmax = next(b for b in ((1, 8), (2, 10), (4, 16), (7, 21), (16, 32)) if win <= b[1])
+    full = "true" if seglen == nseg and segs * seglen == win else "false"
+    cap = "_104" if nseg == 7 else ""
+    return f"k_pyrlk{cap}<{nseg},{wmax},true,{full}>", f"k_pyrlk_cells{cap}<{nseg},{wmax},{full}>"
+
+
+def metric_name(config, homography):
+    """BASELINE.json's metric is quoted on configs[1]; the other configurations are labelled as what they are"""
+    if homography:
+        return "frames/sec @1080p with 4k PyrLK tracks + RANSAC homography (BASELINE configs[4], not the headline)"
+    return {"c1": "frames/sec @640x480 with 2k PyrLK tracks (BASELINE configs[0], not the headline)",
+            "c2": "frames/sec @1080p with 4k PyrLK tracks",
+            "c3": "frames/sec @4K with 10k PyrLK tracks, FAST track (BASELINE configs[2], not the headline)"}[config]
 
 
 def shard_streams(total_streams, world_size, rank):
@@ -132,6 +153,10 @@ def cpu_baseline(frames_rgbx, params, budget_s=10.0):
                       f"scalar build, 1 thread, median of {one_n} frames after 2 warm-ups (time-bounded)"}
 
 
+def ratio(a, b):
+    return (a / b) if (a is not None and b) else None
+
+
 def load_profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
@@ -155,9 +180,33 @@ def profiled_launch_ms(kernel):
     return None
 
 
-def launch_ranks(args, argv):
+def host_cores():
+    """The CPU share this job may use: the scheduler affinity mask, cut down by a cgroup CPU quota when there is one.  (On the GPU
+    boxes os.cpu_count() shows the whole machine; host threads beyond the share only take turns on its cores.)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def default_streams(cfg, world, cores):
+    """Camera streams per GPU.  One GPU: the configuration's own count (32; 16 for 4K).  Several GPUs on one host: every stream has a
+    host thread that polls for its frame's end, so the ranks share the host's cores -- 8 streams already saturate a GPU
+    (profiles/r02_stream_sweep.txt: 4 -> 38.3 k, 8 -> 39.2 k, 32 -> 38.9 k frames/s), and 8 x 32 polling threads do not fit a host."""
+    if world <= 1:
+        return cfg["streams"]
+    return min(cfg["streams"], max(4, cores // world))
+
+
+def launch_ranks(args, argv, poll_s=0.05):
     """--gpus N with no launcher: start the N ranks as fresh child processes (this parent never touches a GPU, and
-    nothing that has initialised a GPU is ever re-executed).  Rank 0's stdout carries the JSON line."""
+    nothing that has initialised a GPU is ever re-executed).  Rank 0's stdout carries the JSON line.  The first rank that
+    ends with an error ends the job: its siblings (which would otherwise wait in the process group for it until the
+    group's timeout) are terminated, and the launcher returns that rank's exit code."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -166,8 +215,35 @@ def launch_ranks(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), LOCAL_WORLD_SIZE=str(args.gpus))
         children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    codes = [c.wait() for c in children]
-    return max(abs(c) for c in codes)
+    deadline = time.monotonic() + args.launch_timeout
+    failed = 0
+    try:
+        while True:
+            codes = [c.poll() for c in children]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, failed = bad[0]
+                print(f"bench.py: rank {r} ended with exit code {failed}; ending the other ranks", file=sys.stderr, flush=True)
+                break
+            if all(c == 0 for c in codes):
+                return 0
+            if time.monotonic() > deadline:
+                failed = 124
+                print(f"bench.py: ranks still running after {args.launch_timeout:.0f} s; ending them", file=sys.stderr, flush=True)
+                break
+            time.sleep(poll_s)
+    finally:
+        live = [c for c in children if c.poll() is None]
+        for c in live:
+            c.terminate()
+        t_kill = time.monotonic() + 5.0
+        for c in live:
+            try:
+                c.wait(timeout=max(0.0, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                c.kill()
+                c.wait()
+    return abs(failed) or 1
 
 
 def main():
@@ -177,7 +253,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 = BASELINE configs[1], the headline (default); c1 = configs[0] (640x480, demo ini); c3 = configs[2] (4K, FAST, 10k features)")
-    ap.add_argument("--streams", type=int, default=0, help="camera streams per GPU (default: 32; 16 for c3)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="camera streams per GPU (default: 32; 16 for c3; with --gpus N > 1: min(that, max(4, host cores // N)))")
     ap.add_argument("--ring", type=int, default=0, help="pre-generated frames resident in HBM (default: 64, SURVEY.md section 8d; 16 for c3)")
     ap.add_argument("--api", choices=["ovx", "thin"], default="ovx",
                     help="ovx: OpenVX graph API (default, the north-star path); thin: nvxcu primitives")
@@ -191,12 +268,15 @@ def main():
                     help="BASELINE configs[4]: append nvxFindHomographyNode (batched RANSAC on the PyrLK matches, the video "
                          "stabilizer's arguments) to every stream's graph; a separate workload, never the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=-1,
+                    help="after the timed block, repeat it this many times for repeat_frames_per_s (default: 15, fewer when a block is long)")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="--gpus N without a launcher: end the ranks after this many seconds")
+    ap.add_argument("--pg-timeout", type=float, default=120.0, help="process-group timeout in seconds (a rank that never arrives is an error)")
     ap.add_argument("--dry-run", action="store_true",
                     help="print this rank's device and camera streams as one JSON line and exit (no GPU is touched)")
     ap.add_argument("--dry-run-devices", type=int, default=0, help="--dry-run: pretend the node has this many GPUs (default: --gpus)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
-    args.streams = args.streams or cfg["streams"]
     args.ring = args.ring or cfg["ring"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -207,6 +287,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    cores = host_cores()
+    args.streams = args.streams or default_streams(cfg, world, cores)
+    if os.environ.get("VSA_BENCH_TEST_FAIL_RANK") == str(rank):     # tests/test_bench_sharding.py: a rank that dies at start-up
+        sys.exit(3)
 
     # weak scaling: S streams on every GPU; global stream ids sharded round-robin over ranks
     my_streams = shard_streams(args.streams * world, world, rank)
@@ -215,7 +299,8 @@ def main():
 
     if args.dry_run:
         dev = rank_device(local_rank, args.dry_run_devices or args.gpus)
-        print(json.dumps({"rank": rank, "world": world, "device": dev, "streams": my_streams, "phases": phases}), flush=True)
+        print(json.dumps({"rank": rank, "world": world, "device": dev, "streams": my_streams, "phases": phases,
+                          "host_cores": cores, "host_threads_total": len(my_streams) * world}), flush=True)
         return
 
     import numpy as np
@@ -232,7 +317,8 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.pg_timeout))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     local_device = rank_device(local_rank, torch.cuda.device_count())
     torch.cuda.set_device(local_device)
@@ -374,8 +460,25 @@ def main():
         if args.homography:
             hs, hn = node_perf(trackers[0].hg)
             hg_ms = hs / max(hn, 1) * 1e-6
+
+    # The spread of the figure: the same block (same steps, same barriers and synchronisation) again, back to back.  `value` stays the
+    # first block's; a block of 20 steps is ~18 ms of GPU time, and how the streams' kernels interleave from a standing start differs
+    # from block to block, so one block alone cannot show a regression of a few percent.
+    n_rep = args.repeats if args.repeats >= 0 else max(3, min(15, int(8.0 / max(elapsed, 1e-3))))
+    rep_fps = []
+    k_next = args.warmup + args.steps
+    for _ in range(n_rep):
+        barrier(world)
+        r0 = time.perf_counter()
+        run(k_next, args.steps)
+        torch.cuda.synchronize()
+        r_el = time.perf_counter() - r0
+        barrier(world)
+        rep_fps.append(args.steps * args.streams * world / reduce_max(r_el, world))
+        k_next += args.steps
+
+    if args.api == "ovx":
         solo = make_driver(trackers[:1], phases[:1]) if driver else None
-        k_next = args.warmup + args.steps
         if solo:
             ovx.check(drv.vsa_driver_run(solo, k_next, 10), "solo warm-up")
             s2, n2 = node_perf(trackers[0].lk)
@@ -393,7 +496,7 @@ def main():
             lk_loaded_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
         trackers[0].lk_events = []
         for k in range(60):
-            trackers[0].track(ring[(phases[0] + 1 + args.warmup + args.steps + k) % args.ring].desc)
+            trackers[0].track(ring[(phases[0] + 1 + k_next + k) % args.ring].desc)
         torch.cuda.synchronize()
         lk_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in trackers[0].lk_events[10:]]))
 
@@ -404,15 +507,16 @@ def main():
         fps = frames / elapsed
         # The OpenVX graph runs the HarrisTrack node's cell pass inside the PyrLK launch (vxVerifyGraph's node fusion): the dominant
         # kernel is then PyrLK + cell pass, and its algorithmic bytes are PyrLK's plus the detector's read of level 0
-        fused = args.api == "ovx" and cfg["harris"] and cfg["lk_cells_kernel"] and not os.environ.get("VISUALSLAM_AMD_NO_FUSION")
+        lk_alone_name, lk_cells_name = lk_kernel_names(cfg["win"])
+        fused = args.api == "ovx" and cfg["harris"] and "VISUALSLAM_AMD_NO_FUSION" not in os.environ
         lk_bytes = B["lk"] + (W * H if fused else 0)
-        lk_name = cfg["lk_cells_kernel"] if fused else cfg["lk_kernel"]
+        lk_name = lk_cells_name if fused else lk_alone_name
         lk_what = "PyrLK + HarrisTrack cell pass" if fused else "PyrLK"
         lk_gbs = lk_bytes / (max(lk_alone_ms, 1e-9) * 1e-3) / 1e9
         counters = load_profile_json("frame_counters.json") if args.config == "c2" and not args.homography and fused else None
         lk_counters = (counters or {}).get("by_kernel", {}).get("k_pyrlk", {})
         out = {
-            "metric": "frames/sec @1080p with 4k PyrLK tracks",
+            "metric": metric_name(args.config, args.homography),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -423,6 +527,10 @@ def main():
                        "frame_ring": args.ring, "api": api_desc,
                        "graph_stream_priority": os.environ["VISUALSLAM_AMD_STREAM_PRIORITY"] if args.api == "ovx" else None},
             "per_rank_frames_per_s": rank_fps,
+            "repeat_frames_per_s": ({"median": float(np.median(rep_fps)), "min": min(rep_fps), "max": max(rep_fps), "blocks": len(rep_fps),
+                                     "note": "the timed block run again back to back (same steps, barriers and synchronisation); "
+                                             "value / ms_per_step are the first block's"} if rep_fps else None),
+            "host_cores": cores, "host_threads_total": args.streams * world if (args.api == "ovx" and args.host_threads) else world,
             "tracks_per_sec": fps * float(np.mean(n_tracks)),
             "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),
             "frame_algorithmic_GBps": bytes_frame * fps / 1e9,
@@ -433,6 +541,9 @@ def main():
             "roofline": {"kernel": f"{lk_name} ({lk_what}, {cfg['capacity']} points x {cfg['levels']} levels, {cfg['win']}x{cfg['win']})",
                          "bound": "hbm", "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
                          "traffic": lk_counters.get("hbm_bytes"), "launch_ms": lk_alone_ms,
+                         # SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE and SQ_INSTS_SALU / SQ_INSTS_VALU of this kernel (profiles/frame_counters.json)
+                         "lds_bank_conflict_frac": ratio(lk_counters.get("lds_bank_conflict_cycles"), lk_counters.get("lds_active_cycles")),
+                         "salu_per_valu": ratio(lk_counters.get("salu_wave_instructions"), lk_counters.get("valu_wave_instructions")),
                          "launch_ms_in_timed_region": lk_loaded_ms, "algorithmic_bytes_per_launch": lk_bytes,
                          "launch_ms_rocprof_single_stream": profiled_launch_ms(lk_name) if args.config == "c2" and not args.homography else None},
         }

@@ -85,11 +85,68 @@ def test_launcher_spawns_one_rank_per_gpu_dry_run():
     assert [d["streams"] for d in lines] == [[0, 4, 8], [1, 5, 9], [2, 6, 10], [3, 7, 11]]   # stream s -> rank s % N
     assert all(len(d["phases"]) == 3 and all(0 <= ph < 8 for ph in d["phases"]) for d in lines)
     # a rehearsal on a box with fewer GPUs than ranks: ranks share devices round-robin
-    lines = sorted(_run_bench("--gpus", "4", "--dry-run", "--dry-run-devices", "1"), key=lambda d: d["rank"])
+    lines = sorted(_run_bench("--gpus", "4", "--streams", "32", "--dry-run", "--dry-run-devices", "1"), key=lambda d: d["rank"])
     assert [d["device"] for d in lines] == [0, 0, 0, 0] and all(len(d["streams"]) == 32 for d in lines)
     # N = 1 needs no children; the defaults are BASELINE configs[1]'s
     (one,) = _run_bench("--dry-run")
+    cores = one.pop("host_cores")
+    assert cores == bench_host_cores() and one.pop("host_threads_total") == 32
     assert one == {"rank": 0, "world": 1, "device": 0, "streams": list(range(32)), "phases": [(3 * s) % 64 for s in range(32)]}
+
+
+def bench_host_cores():
+    import bench
+    return bench.host_cores()
+
+
+def test_streams_per_gpu_follow_the_host_cores_when_ranks_share_a_host():
+    """Every camera stream has a polling host thread: 8 ranks x 32 streams would be 256 threads on one host, while 8 streams already
+    saturate a GPU (profiles/r02_stream_sweep.txt).  One GPU keeps the configuration's own count."""
+    import bench
+    c2, c3 = bench.CONFIGS["c2"], bench.CONFIGS["c3"]
+    assert bench.default_streams(c2, 1, 16) == 32 and bench.default_streams(c3, 1, 16) == 16
+    assert bench.default_streams(c2, 8, 128) == 16 and bench.default_streams(c2, 8, 64) == 8
+    assert bench.default_streams(c2, 8, 16) == 4 and bench.default_streams(c2, 2, 8) == 4      # never below a hardware queue each
+    assert bench.default_streams(c2, 2, 256) == 32 and bench.default_streams(c3, 8, 256) == 16  # never above the configuration's
+    # the launcher at --gpus 8 (dry run): the reduced count reaches every rank and the line says how many host threads that is
+    cores = bench.host_cores()
+    want = bench.default_streams(c2, 8, cores)
+    lines = sorted(_run_bench("--gpus", "8", "--dry-run"), key=lambda d: d["rank"])
+    assert len(lines) == 8 and all(len(d["streams"]) == want for d in lines) and want < 32
+    assert all(d["host_cores"] == cores and d["host_threads_total"] == 8 * want for d in lines)
+    assert sorted(s for d in lines for s in d["streams"]) == list(range(8 * want))
+
+
+def test_a_rank_that_dies_ends_the_job_within_seconds():
+    """One dead rank (busy GPU, out of memory) must not leave its siblings waiting in the process group until a timeout: the
+    launcher terminates them and returns the failed rank's exit code.  Rank 1 exits 3 at start-up; rank 0 is by then waiting in
+    init_process_group for it (gloo, before any GPU call, so this runs on CPU)."""
+    import subprocess
+    import time
+    e = dict(os.environ, VSA_BENCH_TEST_FAIL_RANK="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    t0 = time.monotonic()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=100, env=e)
+    took = time.monotonic() - t0
+    assert res.returncode == 3, (res.returncode, res.stderr[-2000:])
+    assert "rank 1 ended with exit code 3" in res.stderr
+    assert took < 60, took                                   # seconds (python + torch start-up), not the process group's timeout
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")]      # no JSON line from a failed job
+
+
+def test_a_rank_that_never_arrives_trips_the_process_group_timeout():
+    """Under an external launcher (torchrun) there is no sibling watch of ours: the process group's own timeout is the backstop."""
+    import subprocess
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    e = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pg-timeout", "3"],
+                         capture_output=True, text=True, timeout=100, env=e)
+    assert res.returncode != 0 and ("imeout" in res.stderr or "timed out" in res.stderr.lower()), res.stderr[-2000:]
 
 
 def test_torchrun_style_environment_is_respected_dry_run():
