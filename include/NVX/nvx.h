@@ -8,6 +8,8 @@
 #define NVX_NVX_H
 
 #include <VX/vx.h>
+#include <VX/vxu.h>   /* the samples reach the vxu* calls through this header: samples/sfm/SfM.cpp:961-962 calls vxuColorConvert and
+                       * vxuGaussianPyramid with <NVX/nvx.h> (via its nvxio headers) as its only OpenVX include */
 
 #ifdef __cplusplus
 extern "C" {
@@ -37,6 +39,10 @@ enum nvx_graph_attribute_e { NVX_GRAPH_VERIFY_OPTIONS = 0x80280 };
 /* device-pointer mapping for vxMapImagePatch / vxMapArrayRange (the reference's NVX_MEMORY_TYPE_CUDA,
  * nvxio/src/OVX/Private/TypesOVX.cpp:60,93): ptr is the HBM address, stride_y the device pitch */
 enum nvx_memory_type_e { NVX_MEMORY_TYPE_HIP = 0x0E100 };
+
+/* usages of the OpenVX 1.0 accessors (vxAccessArrayRange / vxCommitArrayRange) that hand out the HBM address instead of a host
+ * copy (the reference's NVX_READ_ONLY_CUDA / NVX_WRITE_ONLY_CUDA, VisionWorks-SFM-0.90-Samples/samples/sfm/SfM.cpp:769,776) */
+enum nvx_accessor_e { NVX_READ_ONLY_HIP = 0x80400, NVX_WRITE_ONLY_HIP, NVX_READ_AND_WRITE_HIP };
 
 /* context creation failures reported through vxGetStatus((vx_reference)context)
  * (the reference's NVX_ERROR_NO_CUDA_GPU, nvxio/src/OVX/UtilityOVX.cpp:92-99) */

@@ -189,8 +189,11 @@ nvxcu_error_status_e nvxcuHarrisTrack(const nvxcu_image_t *input, const nvxcu_ar
  * (8 bytes x NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS = 512 KiB per GPU, held until the process ends), and the call
  * allocates nothing.  Limits: ceil(width / cell_size) * ceil(height / cell_size) <= NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS,
  * else NVXCU_ERROR_NO_MEMORY (1080p and 4K frames at cell 18 use 6 420 and 25 680 cells).  The device that owns
- * exec_target's stream must be the current device.  All calls on one GPU share that GPU's array: calls that overlap
- * on one GPU (two streams, two threads) race -- serialise them or use nvxcuHarrisTrack with separate tmp_bufs. */
+ * exec_target's stream must be the calling thread's current device, else NVXCU_ERROR_INVALID_PARAMETERS (checked with
+ * hipStreamGetDevice).  The first call on a GPU looks up the array's address there (hipGetSymbolAddress, which may load
+ * the library's code object): make one call on each GPU outside stream capture before capturing calls into a HIP
+ * graph; every later call is launches and one table read.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (two streams, two threads) race -- serialise them or use nvxcuHarrisTrack with separate tmp_bufs. */
 #define NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS 65536u
 nvxcu_error_status_e nvxcuHarrisTrack_NoAlloc(const nvxcu_image_t *input, const nvxcu_array_t *output,
                                               const nvxcu_image_t *mask, const nvxcu_array_t *tracked_points,

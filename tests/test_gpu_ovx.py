@@ -508,3 +508,85 @@ def test_graph_streams_created_with_a_priority(gpu, monkeypatch, prio):
         _run_sequence(c, p, w, h, _frames(w, h, 3, seed=5))
     finally:
         assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
+
+
+# --------------------------------------------------------------------------- the SFM sample's front end
+@pytest.mark.parametrize("use_mask", [False, True])
+@pytest.mark.parametrize("fusion", [True, False])
+def test_sfm_front_end_graph_matches_oracle(gpu, monkeypatch, use_mask, fusion):
+    """The front end of nvx::SfM (VisionWorks-SFM-0.90-Samples/samples/sfm/SfM.cpp:623-704, 956-1003, 1077-1078) -- a virtual grey
+    image the pyramid is built FROM, delays aged before the parameters are set, the mask set only when non-NULL, Harris with
+    sfm_config.ini's k 0.01 / threshold 5.0 / cell 18, window 10, 6 levels -- frame by frame against the oracle.  With fusion the
+    runtime makes the virtual image a view of level 0, and the graph runs as the feature tracker's does (colour convert inside
+    the pyramid's first launch, cell pass inside the PyrLK launch); without, as seven separate steps.  Same bytes either way."""
+    from visualslam_amd.vx_tracker import VxSfmFrontEnd
+    if not fusion:
+        monkeypatch.setenv("VISUALSLAM_AMD_NO_FUSION", "1")
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    try:
+        w, h, n = 643, 481, 6
+        frames = _frames(w, h, n, seed=91)
+        p = Params(pyr_levels=6, lk_num_iters=5, lk_win_size=10, array_capacity=1200, detector_cell_size=18,
+                   use_harris_detector=True, harris_k=0.01, harris_thresh=5.0)
+        imgs = []
+        for f in frames:
+            img = L.vxCreateImage(c, w, h, ovx.VX_DF_IMAGE_RGBX)
+            ovx.write_image(img, f)
+            imgs.append(img)
+        mask_np, mask = None, None
+        if use_mask:
+            mask_np = np.zeros((h, w), np.uint8)
+            mask_np[h // 5: 4 * h // 5, w // 6: 5 * w // 6] = 255
+            mask = L.vxCreateImage(c, w, h, ovx.VX_DF_IMAGE_U8)
+            ovx.write_image(mask, mask_np)
+        trk = VxSfmFrontEnd(c, p, w, h, imgs[0], mask)
+        fz = ovx.graph_fusions(trk.g)
+        assert fz == ({"color_convert_in_pyramid": 1, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 1} if fusion else
+                      {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 0, "virtual_gray_is_level0": 0})
+        ref = OracleTracker(p)
+        ref.init(frames[0], mask_np)
+        np.testing.assert_array_equal(trk.merged(), ref.prev_pts)
+        for t in range(1, n):
+            # the mask argument alternates between the mask and NULL: NULL must leave the node's mask in place (SfM.cpp:658)
+            n_prev = trk.track(imgs[t], mask if (t % 2) else None)
+            old, cur = ref.track(frames[t], mask_np)
+            assert n_prev == len(old) and n_prev > 200
+            assert trk.prev().tobytes() == old.tobytes(), f"frame {t}: previous features"
+            assert trk.curr().tobytes() == cur.tobytes(), f"frame {t}: tracked features"
+            assert trk.merged().tobytes() == ref.prev_pts.tobytes(), f"frame {t}: merged features"
+    finally:
+        assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
+
+
+def test_legacy_array_accessors_hand_out_device_addresses(ctx):
+    """sfm/SfM.cpp:762-780: the point cloud is copied into another array ON THE DEVICE -- vxTruncateArray, vxAccessArrayRange(...
+    NVX_READ_ONLY_CUDA), vxAddArrayItems of as many placeholder items, vxAccessArrayRange(... NVX_WRITE_ONLY_CUDA), a
+    device-to-device memcpy between the two addresses, vxCommitArrayRange x 2.  (HIP spellings)"""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    src = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT3F, 64)
+    dst = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT3F, 64)
+    cloud = np.arange(3 * 40, dtype=np.float32).reshape(40, 3) * 0.5
+    ovx.check(L.vxAddArrayItems(src, 40, cloud.ctypes.data, 12))
+    stale = np.full((7, 3), -1.0, np.float32)
+    ovx.check(L.vxAddArrayItems(dst, 7, stale.ctypes.data, 12))
+    ovx.check(L.vxTruncateArray(dst, 0))
+    s_stride, s_ptr = C.c_size_t(0), C.c_void_p(None)
+    ovx.check(L.vxAccessArrayRange(src, 0, 40, C.byref(s_stride), C.byref(s_ptr), ovx.NVX_READ_ONLY_HIP))
+    placeholder = np.zeros((40, 3), np.float32)
+    ovx.check(L.vxAddArrayItems(dst, 40, placeholder.ctypes.data, 12))
+    d_stride, d_ptr = C.c_size_t(0), C.c_void_p(None)
+    ovx.check(L.vxAccessArrayRange(dst, 0, 40, C.byref(d_stride), C.byref(d_ptr), ovx.NVX_WRITE_ONLY_HIP))
+    assert s_stride.value == d_stride.value == 12 and s_ptr.value and d_ptr.value and s_ptr.value != d_ptr.value
+    assert hip.hipMemcpy(d_ptr, s_ptr, 40 * 12, 3) == 0              # hipMemcpyDeviceToDevice
+    ovx.check(L.vxCommitArrayRange(src, 0, 40, s_ptr))
+    ovx.check(L.vxCommitArrayRange(dst, 0, 40, d_ptr))
+    assert L.vxCommitArrayRange(dst, 0, 40, d_ptr) == ovx.VX_ERROR_INVALID_PARAMETERS      # each access is committed once
+    got = ovx.read_array(dst, np.float32).reshape(-1, 3)
+    np.testing.assert_array_equal(got, cloud)
+    # a host access of the same range still gives a host copy
+    h_stride, h_ptr = C.c_size_t(0), C.c_void_p(None)
+    ovx.check(L.vxAccessArrayRange(dst, 1, 3, C.byref(h_stride), C.byref(h_ptr), ovx.VX_READ_ONLY))
+    np.testing.assert_array_equal(np.ctypeslib.as_array(C.cast(h_ptr, C.POINTER(C.c_float)), (6,)), cloud[1:3].reshape(-1))
+    ovx.check(L.vxCommitArrayRange(dst, 1, 3, h_ptr))

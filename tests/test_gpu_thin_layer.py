@@ -417,21 +417,13 @@ def test_pyrlk_full_size_config(gpu):
     assert abs(np.median(d[:, 0]) - 0.8) < 0.05 and abs(np.median(d[:, 1]) - 0.5) < 0.05
 
 
-# --------------------------------------------------------------------------- a C++ caller of the thin layer
-@pytest.mark.parametrize("detector,noalloc,use_mask", [("harris", 0, False), ("fast", 0, True), ("harris", 1, True)])
-def test_cpp_thin_layer_application(gpu, tmp_path, detector, noalloc, use_mask):
-    """visualslam_amd/lib/ftcu_hip (shim/ftcu_hip_main.cpp): the thin-layer application of
-    demos/feature_tracker_nvxcu/feature_tracker_nvxcu.cpp:102-179,255-321,387-484 as a C++ program on HIP -- hipMallocPitch
-    images, device-resident counts, nvxcu_stream_exec_target_t with hipDeviceProp_t filled by hipGetDeviceProperties, one
-    stream synchronisation per frame.  The structs are laid out by the C++ compiler from include/NVX/nvxcu.h, not by
-    ctypes mirrors; every frame's point lists must be the oracle's."""
-    import os
+# --------------------------------------------------------------------------- C++ callers of the thin layer
+def _run_cpp_tracker(exe, tmp_path, detector, use_mask, extra_cfg=()):
+    """runs a C++ thin-layer application (frames.rgbx W H N out.bin key=value ...) on a seeded sequence and compares the
+    point lists it writes after every track() -- previous and current features -- with the oracle's, byte for byte"""
     import subprocess
     from oracle.pipeline import OracleTracker
     from visualslam_amd.thin_tracker import Params
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "visualslam_amd", "lib", "ftcu_hip")
-    assert os.path.exists(exe), "visualslam_amd/lib/ftcu_hip is missing: built by visualslam_amd/csrc/Makefile"
     w, h, n = 643, 481, 6                      # odd sizes: hipMallocPitch pads the rows, level sizes round up
     base = synth.base_frame(w, h, 17)
     frames = [synth.to_rgbx(synth.gray_frame(base, t, 17)) for t in range(n)]
@@ -446,7 +438,8 @@ def test_cpp_thin_layer_application(gpu, tmp_path, detector, noalloc, use_mask):
         (tmp_path / "mask.u8").write_bytes(mask.tobytes())
         extra.append(f"mask={tmp_path / 'mask.u8'}")
     cfg = dict(pyr_levels=5, lk_num_iters=5, lk_win_size=21 if detector == "harris" else 10, array_capacity=1500,
-               detector_cell_size=18, detector=detector, harris_k=0.04, harris_thresh=100.0, fast_type=9, fast_thresh=25, noalloc=noalloc)
+               detector_cell_size=18, detector=detector, harris_k=0.04, harris_thresh=100.0, fast_type=9, fast_thresh=25)
+    cfg.update(extra_cfg)
     cmd = [exe, str(fpath), str(w), str(h), str(n), str(opath)] + [f"{k}={v}" for k, v in cfg.items()] + extra
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
@@ -465,6 +458,36 @@ def test_cpp_thin_layer_application(gpu, tmp_path, detector, noalloc, use_mask):
             assert cnt == len(want) and cnt > 100
             assert got.tobytes() == want.tobytes(), f"frame {t}"
     assert off == raw.size
+
+
+@pytest.mark.parametrize("detector,use_mask", [("harris", False), ("harris", True), ("fast", False), ("fast", True)])
+def test_reference_thin_layer_tracker_compiled_from_its_source(gpu, tmp_path, detector, use_mask):
+    """oracle/_ref/ftcu_headless: the reference's OWN thin-layer caller -- nvxcu::FeatureTracker,
+    demos/feature_tracker_nvxcu/feature_tracker_nvxcu.cpp:102-484 (+ .hpp, + nvxio/include/NVX/Utility.hpp for its
+    CUDA_SAFE_CALL / NVXCU_SAFE_CALL / ASSERT macros) -- compiled where it lies against include/NVX/nvxcu.h with the mechanical
+    cuda* -> hip* rename of its runtime calls (oracle/Makefile.ref) and linked with
+    libvisualslam_amd.  Its allocation helpers, the *_GetBufSize scratch protocol, the size_t num_items_dev_ptr_, the
+    count + payload copies that seed PyrLK's output array (:288-295) and its one stream synchronisation per frame (:320)
+    are the reference's code, not a restatement.  shim/ftcu_ref_main.cpp is the frame loop of
+    main_feature_tracker_nvxcu.cpp:236-346 without the GStreamer / OpenGL I/O.  getPrevFeatures() / getCurrFeatures() after every
+    track() must be the oracle's lists, Harris and FAST, with and without a mask."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "ftcu_headless")
+    assert os.path.exists(exe), "oracle/_ref/ftcu_headless is missing: built by oracle/Makefile.ref"
+    _run_cpp_tracker(exe, tmp_path, detector, use_mask)
+
+
+def test_cpp_thin_layer_application_no_alloc(gpu, tmp_path):
+    """visualslam_amd/lib/ftcu_hip (shim/ftcu_hip_main.cpp): our own C++ thin-layer program, kept for the one variant the
+    reference's class cannot show -- the Harris detector through nvxcuHarrisTrack_NoAlloc (no tmp_buf) -- and, with noalloc=0,
+    as the same program on the regular entry point."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "visualslam_amd", "lib", "ftcu_hip")
+    assert os.path.exists(exe), "visualslam_amd/lib/ftcu_hip is missing: built by visualslam_amd/csrc/Makefile"
+    _run_cpp_tracker(exe, tmp_path, "harris", True, extra_cfg=dict(noalloc=1))
+    _run_cpp_tracker(exe, tmp_path, "fast", True, extra_cfg=dict(noalloc=0))
 
 
 # --------------------------------------------------------------------------- the reference's object tracker on the thin layer

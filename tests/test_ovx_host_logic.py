@@ -757,3 +757,54 @@ def test_openvx_1_0_kernel_api(ctx):
     assert L.vxSetParameterByIndex(n, 0, L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)) == 0
     assert L.vxVerifyGraph(g) == ovx.VX_ERROR_INVALID_PARAMETERS
     assert L.vxGetStatus(L.vxGetParameterByIndex(n, 2)) == ovx.VX_ERROR_INVALID_PARAMETERS
+
+
+def _sfm_graph(ctx, virtual=True, second_pyramid=False, w=320, h=240, unsized=False):
+    """front-end nodes of nvx::SfM::createMainGraph (VisionWorks-SFM-0.90-Samples/samples/sfm/SfM.cpp:970-1003,1077-1078) and of the
+    stabilizer (video_stabilizer/stabilizer.cpp:237-260): a (virtual) grey image that the pyramid is built FROM"""
+    frame = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_RGBX)
+    pex = L.vxCreatePyramid(ctx, 4, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
+    pyr_delay = L.vxCreateDelay(ctx, pex, 2)
+    aex = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 500)
+    pts_delay = L.vxCreateDelay(ctx, aex, 2)
+    kp = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, 500)
+    g = L.vxCreateGraph(ctx)
+    gw, gh = (0, 0) if unsized else (w, h)
+    gray = L.vxCreateVirtualImage(g, gw, gh, ovx.VX_DF_IMAGE_U8) if virtual else L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
+    pyr0 = L.vxGetReferenceFromDelay(pyr_delay, 0)
+    eps, it, est = ovx.scalar(ctx, ovx.VX_TYPE_FLOAT32, 0.01), ovx.scalar(ctx, ovx.VX_TYPE_UINT32, 5), ovx.scalar(ctx, ovx.VX_TYPE_BOOL, 0)
+    nodes = [L.nvxHarrisTrackNode(g, gray, L.vxGetReferenceFromDelay(pts_delay, 0), None, kp, 0.01, 5.0, 18, None),
+             L.vxOpticalFlowPyrLKNode(g, L.vxGetReferenceFromDelay(pyr_delay, -1), pyr0, L.vxGetReferenceFromDelay(pts_delay, -1),
+                                      L.vxGetReferenceFromDelay(pts_delay, -1), kp, ovx.VX_TERM_CRITERIA_BOTH, eps, it, est, 10),
+             L.vxGaussianPyramidNode(g, gray, pyr0),
+             L.vxColorConvertNode(g, frame, gray)]
+    if second_pyramid:
+        nodes.append(L.vxGaussianPyramidNode(g, gray, pex))
+    for n in nodes:
+        assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+    return g, gray
+
+
+def test_virtual_grey_image_becomes_level_0_of_the_pyramid_it_feeds(ctx, monkeypatch):
+    """A virtual image is one the application never accesses (OpenVX): the runtime gives the stabilizer's and the SFM sample's
+    virtual grey frame no memory of its own but makes it a view of level 0 of the pyramid built from it, so their graphs run
+    with the feature tracker's fusions.  A real image, or a grey image feeding two pyramids, keeps its own memory."""
+    order = [ovx.K_COLOR_CONVERT, ovx.K_GAUSSIAN_PYRAMID, ovx.K_PYRLK, ovx.K_HARRIS_TRACK]
+    for unsized in (False, True):           # the stabilizer's virtual image is created 0 x 0 (stabilizer.cpp:237)
+        g, gray = _sfm_graph(ctx, unsized=unsized)
+        assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS and _order(g) == order
+        assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 1, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 1}
+        assert ovx.query("vxQueryImage", gray, ovx.VX_IMAGE_WIDTH, C.c_uint32) == 320
+        # a second verification starts over and arrives at the same graph
+        assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS and _order(g) == order
+        assert ovx.graph_fusions(g)["virtual_gray_is_level0"] == 1
+    g, _ = _sfm_graph(ctx, virtual=False)
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS and _order(g) == order
+    assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 0}
+    g, _ = _sfm_graph(ctx, second_pyramid=True)
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
+    assert ovx.graph_fusions(g)["virtual_gray_is_level0"] == 0 and ovx.graph_fusions(g)["color_convert_in_pyramid"] == 0
+    monkeypatch.setenv("VISUALSLAM_AMD_NO_FUSION", "1")
+    g, _ = _sfm_graph(ctx)
+    assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS and _order(g) == order
+    assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 0, "virtual_gray_is_level0": 0}

@@ -1,13 +1,15 @@
 """nvxcuHarrisTrack_NoAlloc (include/NVX/nvxcu.h): the entry point that allocates nothing -- its cell keys live in a
-file-scope device array of the library -- against nvxcuHarrisTrack with a caller-owned tmp_buf, through the C ABI.
-Bit-identical outputs are required (corner sets, strengths, counts), on two calls in a row on the same GPU, the
-second with a smaller input (the array keeps the first call's keys), then a third that grows again.
+file-scope device array of the library -- against nvxcuHarrisTrack with a caller-owned tmp_buf AND against the oracle,
+through the C ABI.  Bit-identical outputs are required (corner sets, strengths, counts), on two calls in a row on the same
+GPU, the second with a smaller input (the array keeps the first call's keys), then a third that grows again; and once
+captured into a HIP graph and replayed (the callers the entry point is for).
 Collected last (test_zz_*): `pytest -x` must not hide the other tests behind a failure here."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
+import oracle as O
 from visualslam_amd import nvxcu, synth
 from visualslam_amd.devmem import DeviceArray, DeviceImage, Scratch, current_target
 
@@ -36,6 +38,10 @@ def _both(gray, mask, tracked, item_type, cell, cap, k=0.04, thr=100.0):
     return res
 
 
+def _as_items(tracked, item_type):
+    return tracked          # every case with tracked points uses POINT2F items
+
+
 def _scene(w, h, seed):
     return synth.gray_frame(synth.base_frame(w, h, seed), 0, seed)
 
@@ -61,6 +67,11 @@ def test_noalloc_matches_harris_track_on_consecutive_calls(gpu):
         assert ref[1] > 0 and ref[2] >= ref[1]
         assert got[1:] == ref[1:], (w, h, cell)
         assert got[0] == ref[0], (w, h, cell)
+        # ... and both are the oracle's list: a bug shared by the two entry points' common path would not hide
+        want, want_total, _ = O.harris_track(gray, mask, _as_items(tracked, it), 0.04, 100.0, cell, cap,
+                                             item_type=O.KEYPOINTF if it == nvxcu.NVXCU_TYPE_KEYPOINTF else O.POINT2F)
+        assert (got[1], got[2]) == (len(want), want_total), (w, h, cell)
+        assert got[0] == want.tobytes(), (w, h, cell)
 
 
 def test_noalloc_rejects_grids_beyond_its_array(gpu):
@@ -76,3 +87,47 @@ def test_noalloc_rejects_grids_beyond_its_array(gpu):
     # same argument checks as nvxcuHarrisTrack
     assert nvxcu.harris_track_noalloc(img.desc, out.desc, None, None, 0.04, 100.0, 0, None, current_target()) == \
         nvxcu.NVXCU_ERROR_INVALID_PARAMETERS
+
+
+def test_noalloc_captured_into_a_hip_graph_and_replayed(gpu):
+    """The callers this entry point exists for: code under stream capture cannot allocate.  One plain call first (it looks up
+    the array's address on this GPU, as the header asks), then the call is captured into a HIP graph -- nothing may allocate or
+    synchronise during capture -- and the graph is replayed on two different frames written into the same input buffer."""
+    import torch
+    w, h, cell, cap = 640, 480, 18, 1500
+    scenes = [_scene(w, h, seed=s) for s in (21, 22, 23)]
+    img = DeviceImage(w, h).upload(scenes[0])
+    out = DeviceArray(cap, nvxcu.NVXCU_TYPE_POINT2F)
+    ncorn = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    args = (img.desc, out.desc, None, None, 0.04, 100.0, cell, ncorn.data_ptr())
+    assert nvxcu.harris_track_noalloc(*args, current_target()) == OK           # warm-up outside capture
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        assert nvxcu.harris_track_noalloc(*args, current_target()) == OK
+    for gray in scenes[1:]:
+        img.upload(gray)
+        out.count.zero_()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want, total, _ = O.harris_track(gray, None, None, 0.04, 100.0, cell, cap)
+        n = out.num_items()
+        assert n == len(want) > 100 and int(ncorn.item()) == total
+        assert out.buf[: n * out.item_size].cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_noalloc_refuses_a_stream_of_another_device(gpu):
+    """with one GPU the mismatch cannot be staged; what can be checked is that the stream's own device passes and that a
+    handle that is no stream is an error, not a fault"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        img, out = DeviceImage(64, 48), DeviceArray(10)
+        assert nvxcu.harris_track_noalloc(img.desc, out.desc, None, None, 0.04, 100.0, 18, None, current_target()) == OK
+        torch.cuda.synchronize()
+        return
+    with torch.cuda.device(1):
+        other = nvxcu.StreamExecTarget(torch.cuda.Stream(device="cuda:1").cuda_stream)
+    img, out = DeviceImage(64, 48), DeviceArray(10)
+    assert nvxcu.harris_track_noalloc(img.desc, out.desc, None, None, 0.04, 100.0, 18, None, other) == nvxcu.NVXCU_ERROR_INVALID_PARAMETERS

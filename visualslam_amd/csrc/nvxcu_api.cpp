@@ -22,20 +22,26 @@ static constexpr int kMaxDevices = 64;
 static std::mutex g_scratch_mu;
 static void *g_scratch_ptr[kMaxDevices];      // device address of `scratch` on device i, looked up on first use
 
-// the current device's copy of `scratch`; nullptr (and *err set) when the lookup fails
-static void *static_scratch(hipError_t *err)
+// The copy of `scratch` on the GPU that `stream` belongs to, which must be the calling thread's current device (launches go
+// to the current device's code object; a pointer into another GPU's copy would fault or silently use peer access):
+// *status = NVXCU_ERROR_INVALID_PARAMETERS on a mismatch, NVXCU_FAILURE when a HIP call fails.  The first call on a device
+// looks the address up (hipGetSymbolAddress may load the code object: not something to do under stream capture, so the
+// header asks for one call outside capture first); later calls only read the table.
+static void *static_scratch(hipStream_t stream, nvxcu_error_status_e *status)
 {
     int dev = -1;
-    *err = hipGetDevice(&dev);
-    if (*err != hipSuccess) return nullptr;
-    if (dev < 0 || dev >= kMaxDevices) { *err = hipErrorInvalidDevice; return nullptr; }
+    hipDevice_t sdev = -1;
+    *status = NVXCU_FAILURE;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    if (hipStreamGetDevice(stream, &sdev) != hipSuccess) return nullptr;
+    if ((int)sdev != dev) { *status = NVXCU_ERROR_INVALID_PARAMETERS; return nullptr; }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (!g_scratch_ptr[dev]) {
         void *ptr = nullptr;
-        *err = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
-        if (*err != hipSuccess || !ptr) { if (*err == hipSuccess) *err = hipErrorInvalidSymbol; return nullptr; }
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return nullptr;
         g_scratch_ptr[dev] = ptr;
     }
+    *status = NVXCU_SUCCESS;
     return g_scratch_ptr[dev];
 }
 
@@ -143,9 +149,9 @@ nvxcu_error_status_e corner_track(Detector det, const nvxcu_image_t *input, cons
         // the keys of every cell are rewritten by each call (k_harris_cells stores all of them), so the array needs
         // no clearing between calls although it keeps the previous call's contents
         if (need > sizeof(unsigned long long) * NVXCU_HARRIS_TRACK_NOALLOC_MAX_CELLS) return NVXCU_ERROR_NO_MEMORY;
-        hipError_t e = hipSuccess;
-        keys = static_scratch(&e);
-        if (!keys) return NVXCU_FAILURE;
+        nvxcu_error_status_e st = NVXCU_FAILURE;
+        keys = static_scratch(stream, &st);
+        if (!keys) return st;
     } else {
         if (!tmp || !tmp->dev_ptr || ((uintptr_t)tmp->dev_ptr & 7u)) return need ? NVXCU_ERROR_INVALID_PARAMETERS : NVXCU_FAILURE;
         keys = tmp->dev_ptr;

@@ -193,6 +193,7 @@ struct _vx_graph : _vx_reference {
     std::vector<_vx_array *> written;     // arrays whose counts are read back after a run
     std::vector<_vx_node *> corner_nodes; // nodes with a num_corners scalar to refresh
     std::vector<_vx_matrix *> matrices;   // matrices written by nodes: values come back through pinned slots
+    std::vector<_vx_image *> aliased;     // virtual images this graph's verification made views of a pyramid's level 0
     uint32_t *pinned = nullptr;           // count read-back staging (pinned)
     size_t pinned_slots = 0;
     bool scheduled = false;
@@ -511,6 +512,14 @@ vx_status refresh_count_now(_vx_array *a, hipStream_t stream)
 // ---- node execution ----------------------------------------------------------------------------
 ImageView view_of(const _vx_image *im) { return ImageView{ im->dev, im->pitch, im->width, im->height }; }
 
+// is `gray` the memory of level 0 of `pyr`: the level object itself, or a whole-image view of it (alias_virtual_pyramid_inputs)
+bool is_level0(const _vx_image *gray, const _vx_pyramid *pyr)
+{
+    if (!gray || !pyr || pyr->levels.empty()) return false;
+    const _vx_image *l0 = pyr->levels[0];
+    return gray == l0 || (gray->parent == l0 && gray->roi_x == 0 && gray->roi_y == 0 && gray->width == l0->width && gray->height == l0->height);
+}
+
 vx_status pyramid_view(_vx_pyramid *p, PyramidView *v)
 {
     if (p->levels.empty() || p->levels.size() > (size_t)kMaxPyrLevels) return VX_ERROR_INVALID_PARAMETERS;
@@ -581,7 +590,7 @@ vx_status do_color_pyramid(_vx_image *rgbx, _vx_image *gray, _vx_pyramid *pyr, h
 {
     if (!rgbx || !gray || !pyr) return VX_ERROR_INVALID_PARAMETERS;
     if (rgbx->format == VX_DF_IMAGE_RGBX && rgbx->width == gray->width && rgbx->height == gray->height && gray->format == VX_DF_IMAGE_U8 &&
-        gray->width == pyr->width && gray->height == pyr->height && !pyr->levels.empty() && pyr->levels[0] == gray) {
+        gray->width == pyr->width && gray->height == pyr->height && is_level0(gray, pyr)) {
         PyramidView v{};
         vx_status s = ensure_image(rgbx);
         if (s == VX_SUCCESS) s = pyramid_view(pyr, &v);
@@ -983,11 +992,64 @@ vx_status verify_user_node(_vx_node *nd)
     return VX_SUCCESS;
 }
 
+// The video stabilizer and the SFM sample convert the frame into a VIRTUAL grey image and build the pyramid from that
+// (video_stabilizer/stabilizer.cpp:237-251, sfm/SfM.cpp:980-988) where the feature tracker converts straight into level 0
+// (feature_tracker.cpp:360-362).  "Virtual" tells the runtime that the application never accesses the image, so the runtime
+// gives it no memory of its own: it becomes a whole-image view of level 0 of the pyramid it feeds.  The GaussianPyramid node
+// then has nothing to copy, and the same node fusions apply as in the feature tracker's graph (4 launches per frame instead
+// of 7).  The view follows the pyramid object, so it stays right when a delay ages the pyramid's memory.
+void alias_virtual_pyramid_inputs(_vx_graph *g)
+{
+    for (_vx_image *im : g->aliased)          // a re-verification starts over: node parameters may have changed
+        if (valid(im) && im->parent) { release_ref(im->parent); im->parent = nullptr; im->dev = nullptr; im->pitch = 0; }
+    g->aliased.clear();
+    if (getenv("VISUALSLAM_AMD_NO_FUSION") != nullptr) return;
+    for (_vx_node *gp : g->nodes) {
+        if (gp->kind != K_GAUSSIAN_PYRAMID) continue;
+        auto *gray = param<_vx_image>(gp, 0, VX_TYPE_IMAGE);
+        auto *pyr = param<_vx_pyramid>(gp, 1, VX_TYPE_PYRAMID);
+        if (!gray || !pyr || pyr->levels.empty()) continue;
+        _vx_image *l0 = pyr->levels[0];
+        if (gray == l0 || !gray->is_virtual || gray->parent || gray->dev || gray->pyramid || gray->has_fill) continue;
+        if (gray->format != VX_DF_IMAGE_U8 || l0->format != VX_DF_IMAGE_U8) continue;
+        const bool unsized = gray->width == 0 && gray->height == 0;
+        if (!unsized && (gray->width != l0->width || gray->height != l0->height)) continue;
+        // exactly one node writes the grey image, no other node writes the pyramid, and no other pyramid is built from it
+        int gray_writers = 0;
+        bool clash = false;
+        for (_vx_node *nd : g->nodes)
+            for (size_t p = 0; p < nd->params.size(); ++p) {
+                _vx_reference *r = nd->params[p];
+                if (!r || nd->spec[p].type == VX_TYPE_SCALAR) continue;
+                const bool writes = nd->spec[p].dir != VX_INPUT;
+                if (r == gray && writes) { ++gray_writers; if (nd->kind != K_COLOR_CONVERT && nd->kind != K_COPY_IMAGE) clash = true; }
+                if (r == gray && !writes && nd->kind == K_GAUSSIAN_PYRAMID && nd != gp) clash = true;
+                if (nd != gp && writes) {
+                    std::vector<const void *> keys, mine{ pyr };
+                    keys_of(r, &keys);
+                    for (auto *l : pyr->levels) mine.push_back(l);
+                    if (intersects(keys, mine)) clash = true;
+                }
+            }
+        if (gray_writers != 1 || clash) continue;
+        gray->width = l0->width;
+        gray->height = l0->height;
+        gray->parent = l0;
+        gray->roi_x = gray->roi_y = 0;
+        retain(l0);
+        g->aliased.push_back(gray);
+    }
+}
+
 vx_status verify_graph(_vx_graph *g)
 {
     _vx_context *ctx = g->ctx;
     const size_t n = g->nodes.size();
     if (n == 0) return VX_ERROR_INVALID_GRAPH;
+    // streams and pinned memory created below belong to the context's GPU, whatever device the calling thread last used
+    // (a fresh host thread starts on device 0)
+    if (!ctx->no_device && hipSetDevice(ctx->device) != hipSuccess) return VX_FAILURE;
+    alias_virtual_pyramid_inputs(g);
     std::vector<std::vector<const void *>> rd(n), wr(n);
     for (size_t i = 0; i < n; ++i) {
         _vx_node *nd = g->nodes[i];
@@ -1066,17 +1128,22 @@ vx_status verify_graph(_vx_graph *g)
             if (gp->kind != K_GAUSSIAN_PYRAMID) continue;
             auto *gray = param<_vx_image>(gp, 0, VX_TYPE_IMAGE);
             auto *pyr = param<_vx_pyramid>(gp, 1, VX_TYPE_PYRAMID);
-            if (!gray || !pyr || pyr->levels.size() < 2 || pyr->levels[0] != gray || gray->parent) continue;
+            if (!gray || !pyr || pyr->levels.size() < 2 || !is_level0(gray, pyr)) continue;
             for (size_t ci = 0; ci < n; ++ci) {
                 _vx_node *cv = g->nodes[ci];
                 if (cv->kind != K_COLOR_CONVERT || param<_vx_image>(cv, 1, VX_TYPE_IMAGE) != gray || pos[ci] > pos[gi]) continue;
                 auto *frame = param<_vx_image>(cv, 0, VX_TYPE_IMAGE);
                 if (!frame || frame->format != VX_DF_IMAGE_RGBX) continue;
-                bool ok = true;      // every other reader of the grey image runs after the pyramid node
+                // every other reader of the grey image runs after the pyramid node, and -- the conversion now happens at the
+                // pyramid node's place in the order -- no node between the two writes the colour frame or the grey image
+                bool ok = true;
+                std::vector<const void *> only_gray{ gray }, moved;
+                keys_of(frame, &moved);
+                keys_of(gray, &moved);
                 for (size_t b = 0; b < n && ok; ++b) {
                     if (b == ci || b == gi) continue;
-                    std::vector<const void *> only_gray{ gray };
                     if (intersects(rd[b], only_gray) && pos[b] < pos[gi]) ok = false;
+                    if (pos[b] > pos[ci] && pos[b] < pos[gi] && intersects(wr[b], moved)) ok = false;
                 }
                 if (ok) { cv->fused_away = true; gp->fused_cvt = cv; }
                 break;
@@ -1939,6 +2006,11 @@ vx_status vxAccessArrayRange(vx_array arr, vx_size start, vx_size end, vx_size *
 {
     if (!ptr || *ptr != nullptr) return VX_ERROR_NOT_SUPPORTED;   // user-supplied buffers are not offered
     vx_map_id id;
+    // the NVX usages hand out the HBM address instead of a host copy (sfm/SfM.cpp:769-776: device-to-device copy between arrays)
+    if (usage == NVX_READ_ONLY_HIP || usage == NVX_WRITE_ONLY_HIP || usage == NVX_READ_AND_WRITE_HIP) {
+        const vx_enum u = usage == NVX_READ_ONLY_HIP ? VX_READ_ONLY : usage == NVX_WRITE_ONLY_HIP ? VX_WRITE_ONLY : VX_READ_AND_WRITE;
+        return vxMapArrayRange(arr, start, end, &id, stride, ptr, u, NVX_MEMORY_TYPE_HIP, 0);
+    }
     return vxMapArrayRange(arr, start, end, &id, stride, ptr, usage, VX_MEMORY_TYPE_HOST, 0);
 }
 
@@ -1950,7 +2022,11 @@ vx_status vxCommitArrayRange(vx_array arr, vx_size, vx_size, const void *ptr)
     vx_map_id id = 0;
     {
         std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-        for (auto &m : ctx->maps) if (m.second.obj == a && m.second.host == ptr) { id = m.first; break; }
+        for (auto &m : ctx->maps) {
+            const MapRecord &r = m.second;
+            const void *mapped = r.mem_type == NVX_MEMORY_TYPE_HIP ? (a->dev ? a->dev + r.x0 * a->item_size : nullptr) : r.host;
+            if (r.obj == a && mapped && mapped == ptr) { id = m.first; break; }
+        }
     }
     return id ? vxUnmapArrayRange(arr, id) : VX_ERROR_INVALID_PARAMETERS;
 }
@@ -2733,4 +2809,19 @@ extern "C" int visualslam_amd_graph_order(vx_graph graph, int *kinds, int max_ki
         ++n;
     }
     return n;
+}
+
+/* not part of the reference API: what vxVerifyGraph decided to fuse (for tests): out[0] = ColorConvert nodes converted inside the
+ * pyramid's first launch, out[1] = detector nodes whose cell pass rides in the PyrLK launch, out[2] = virtual grey images made
+ * views of a pyramid's level 0 */
+extern "C" int visualslam_amd_graph_fusions(vx_graph graph, int *out, int max_out)
+{
+    if (!valid(graph, VX_TYPE_GRAPH) || !graph->verified || !out || max_out < 3) return -1;
+    out[0] = out[1] = 0;
+    for (_vx_node *nd : graph->nodes) {
+        if (nd->fused_away) ++out[0];
+        if (nd->fused_cells) ++out[1];
+    }
+    out[2] = (int)graph->aliased.size();
+    return 3;
 }

@@ -22,7 +22,8 @@ VX_TYPE_UINT32, VX_TYPE_FLOAT32, VX_TYPE_SIZE, VX_TYPE_BOOL, VX_TYPE_ENUM = 0x00
 VX_TYPE_KEYPOINT = 0x021
 VX_TYPE_UINT8, VX_TYPE_MATRIX = 0x003, 0x80B
 VX_TYPE_IMAGE, VX_TYPE_ARRAY, VX_TYPE_PYRAMID, VX_TYPE_ERROR = 0x80F, 0x80E, 0x809, 0x811
-NVX_TYPE_POINT2F, NVX_TYPE_KEYPOINTF = 0x400, 0x403
+NVX_TYPE_POINT2F, NVX_TYPE_POINT3F, NVX_TYPE_KEYPOINTF = 0x400, 0x401, 0x403
+NVX_READ_ONLY_HIP, NVX_WRITE_ONLY_HIP, NVX_READ_AND_WRITE_HIP = 0x80400, 0x80401, 0x80402
 VX_DF_IMAGE_U8, VX_DF_IMAGE_RGBX = nvxcu.NVXCU_DF_IMAGE_U8, nvxcu.NVXCU_DF_IMAGE_RGBX
 VX_IMAGE_WIDTH, VX_IMAGE_HEIGHT, VX_IMAGE_FORMAT, VX_IMAGE_PLANES = 0x80F00, 0x80F01, 0x80F02, 0x80F03
 VX_ARRAY_ITEMTYPE, VX_ARRAY_NUMITEMS, VX_ARRAY_CAPACITY, VX_ARRAY_ITEMSIZE = 0x80E00, 0x80E01, 0x80E02, 0x80E03
@@ -160,6 +161,7 @@ _SIGS = {
     "nvxFindHomographyNode": (C.c_void_p, [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
     "nvxuFindHomography": (C.c_int32, [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p]),
     "visualslam_amd_graph_order": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    "visualslam_amd_graph_fusions": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "vxSetNodeAttribute": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "vxCreateUniformImage": (C.c_void_p, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "vxCreateImageFromROI": (C.c_void_p, [C.c_void_p, C.POINTER(vx_rectangle_t)]),
@@ -262,3 +264,12 @@ def add_items(arr, items):
     n = len(items)
     isz = items.dtype.itemsize if items.ndim == 1 else items.dtype.itemsize * items.shape[1]
     check(lib().vxAddArrayItems(arr, n, items.ctypes.data, isz), "vxAddArrayItems")
+
+
+def graph_fusions(graph):
+    """what vxVerifyGraph fused (a debug export, not reference API): ColorConvert nodes converted inside the pyramid's first
+    launch, detector cell passes riding in the PyrLK launch, virtual grey images made views of a pyramid's level 0"""
+    buf = (C.c_int * 3)()
+    n = lib().visualslam_amd_graph_fusions(graph, buf, 3)
+    assert n == 3, "graph not verified"
+    return {"color_convert_in_pyramid": buf[0], "cells_in_pyrlk": buf[1], "virtual_gray_is_level0": buf[2]}

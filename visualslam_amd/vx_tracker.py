@@ -98,3 +98,70 @@ class VxFeatureTracker:
 
     def wait(self):
         ovx.check(L.vxWaitGraph(self.g), "vxWaitGraph")
+
+
+class VxSfmFrontEnd:
+    """The feature-tracking front end of the SFM sample's wrapper, nvx::SfM (VisionWorks-SFM-0.90-Samples/samples/sfm/SfM.cpp),
+    call for call: createDataObjects (:900-957), processFirstFrame (:956-968), the front-end nodes of createMainGraph (:970-1003,
+    1077-1078) and track() (:623-704).  It differs from the feature tracker's graph where the reference's does:
+      * the grey frame is a VIRTUAL image and the pyramid is built FROM it (:977-988) instead of the frame being converted straight
+        into level 0;
+      * the delays are aged BEFORE the frame is validated and the node parameters are set (:625-627);
+      * the mask parameter is set only when a mask is given (:658) -- the node keeps the mask it was created with otherwise;
+      * Harris only, k / threshold / cell from sfm_config.ini (0.01 / 5.0 / 18), window 10, 6 levels.
+    The nvxSfm* nodes between PyrLK and HarrisTrack belong to the closed libvisionworks_sfm and are not part of this path."""
+
+    def __init__(self, ctx, p, w, h, first_frame, mask):
+        self.ctx, self.p = ctx, p
+        pex = L.vxCreatePyramid(ctx, p.pyr_levels, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
+        self.pyr_delay = L.vxCreateDelay(ctx, pex, 2)
+        ovx.release("Pyramid", pex)
+        aex = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, p.array_capacity)
+        self.pts_delay = L.vxCreateDelay(ctx, aex, 2)
+        ovx.release("Array", aex)
+        self.kp_tracked = L.vxCreateArray(ctx, ovx.NVX_TYPE_POINT2F, p.array_capacity)
+        # createMainGraph(firstFrame, mask)
+        self.g = L.vxCreateGraph(ctx)
+        gray = L.vxCreateVirtualImage(self.g, w, h, ovx.VX_DF_IMAGE_U8)
+        assert L.vxGetStatus(gray) == ovx.VX_SUCCESS
+        self.cvt = L.vxColorConvertNode(self.g, first_frame, gray)
+        pyr0 = L.vxGetReferenceFromDelay(self.pyr_delay, 0)
+        self.pyr = L.vxGaussianPyramidNode(self.g, gray, pyr0)
+        eps, it, est = ovx.scalar(ctx, ovx.VX_TYPE_FLOAT32, 0.01), ovx.scalar(ctx, ovx.VX_TYPE_UINT32, p.lk_num_iters), ovx.scalar(ctx, ovx.VX_TYPE_BOOL, 0)
+        self.lk = L.vxOpticalFlowPyrLKNode(self.g, L.vxGetReferenceFromDelay(self.pyr_delay, -1), pyr0,
+                                           L.vxGetReferenceFromDelay(self.pts_delay, -1), L.vxGetReferenceFromDelay(self.pts_delay, -1),
+                                           self.kp_tracked, ovx.VX_TERM_CRITERIA_BOTH, eps, it, est, p.lk_win_size)
+        self.det = L.nvxHarrisTrackNode(self.g, gray, L.vxGetReferenceFromDelay(self.pts_delay, 0), mask, self.kp_tracked,
+                                        p.harris_k, p.harris_thresh, p.detector_cell_size, None)
+        for n in (self.cvt, self.pyr, self.lk, self.det):
+            assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+        ovx.check(L.vxVerifyGraph(self.g), "vxVerifyGraph")
+        for s in (eps, it, est):
+            ovx.release("Scalar", s)
+        ovx.release("Image", gray)
+        # processFirstFrame(firstFrame, mask)
+        fgray = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
+        ovx.check(L.vxuColorConvert(ctx, first_frame, fgray), "vxuColorConvert")
+        ovx.check(L.vxuGaussianPyramid(ctx, fgray, L.vxGetReferenceFromDelay(self.pyr_delay, 0)), "vxuGaussianPyramid")
+        ovx.check(L.nvxuHarrisTrack(ctx, fgray, L.vxGetReferenceFromDelay(self.pts_delay, 0), mask, None,
+                                    p.harris_k, p.harris_thresh, p.detector_cell_size, None), "nvxuHarrisTrack")
+        ovx.release("Image", fgray)
+
+    def track(self, frame, mask):
+        ovx.check(L.vxAgeDelay(self.pyr_delay))                     # SfM.cpp:625-627: aged first
+        ovx.check(L.vxAgeDelay(self.pts_delay))
+        if mask:
+            ovx.check(L.vxSetParameterByIndex(self.det, 2, mask))   # :658: only when there is one
+        ovx.check(L.vxSetParameterByIndex(self.cvt, 0, frame))      # :663
+        n = ovx.num_items(L.vxGetReferenceFromDelay(self.pts_delay, -1))    # :665-666 (feeds the closed RANSAC sampler)
+        ovx.check(L.vxProcessGraph(self.g), "vxProcessGraph")       # :704
+        return n
+
+    def prev(self):
+        return ovx.read_array(L.vxGetReferenceFromDelay(self.pts_delay, -1))
+
+    def curr(self):
+        return ovx.read_array(self.kp_tracked)
+
+    def merged(self):
+        return ovx.read_array(L.vxGetReferenceFromDelay(self.pts_delay, 0))
