@@ -104,16 +104,3 @@ def test_stream_driver_library_loads_and_uses_only_the_public_c_api():
     lib.vsa_drive_streams.restype = ctypes.c_int
     # argument checking only (no context, no device): null handle arrays are refused
     assert lib.vsa_drive_streams(1, None, None, None, None, None, None, 1, None, 0, 1) == -10   # VX_ERROR_INVALID_PARAMETERS
-
-
-def test_fast_cell_pass_row_column_split_is_exact():
-    """visualslam_amd/csrc/corner_track.hip splits an item number into row and column with a multiply and a shift
-    (fast_div_magic / fast_div): (i * (2^22 / d + 1)) >> 22 must be i // d, in 32-bit arithmetic, for every row length d
-    and item number i the FAST tiles can produce: d <= 72 items per row, at most 48 rows (checked for d <= 128, 64 rows)."""
-    import numpy as np
-    for d in range(1, 129):
-        i = np.arange(64 * d, dtype=np.uint64)
-        m = (1 << 22) // d + 1
-        prod = i * np.uint64(m)
-        assert int(prod.max()) < 2 ** 32                     # the kernel multiplies in 32 bits
-        np.testing.assert_array_equal(prod >> np.uint64(22), i // np.uint64(d), err_msg=f"d={d}")

@@ -488,6 +488,24 @@ def test_harris_cell_pass_in_the_pyrlk_launch_or_not(gpu, monkeypatch, win, fusi
         assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
 
 
+@pytest.mark.parametrize("fast_n,win", [(9, 21), (9, 6), (10, 10), (10, 21), (11, 16), (12, 21), (12, 32)])
+@pytest.mark.parametrize("fusion", [True, False])
+def test_fast_cell_pass_in_the_pyrlk_launch_or_not(gpu, monkeypatch, fast_n, win, fusion):
+    """the FastTrack node's cell pass rides in the PyrLK launch like the HarrisTrack node's (feature_tracker.cpp:426-430 is the
+    node): FAST-9 .. 12 x PyrLK window buckets, fused or kept apart, every frame's tracked and merged features the oracle's."""
+    if not fusion:
+        monkeypatch.setenv("VISUALSLAM_AMD_NO_FUSION", "1")
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    try:
+        w, h = 643, 481
+        p = Params(pyr_levels=4, lk_win_size=win, use_harris_detector=False, fast_type=fast_n, fast_thresh=20, array_capacity=1500)
+        trk = _run_sequence(c, p, w, h, _frames(w, h, 4, seed=60 + fast_n + win))
+        assert ovx.graph_fusions(trk.g)["cells_in_pyrlk"] == (1 if fusion else 0)
+    finally:
+        assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
+
+
 def test_cell_pass_is_not_fused_when_its_image_is_written_after_pyrlk_starts(ctx):
     """the detector reads a copy of the grey frame made by a node that runs between PyrLK and the detector: the cell pass must
     wait for it (run fused, it would see the previous frame's copy)"""

@@ -1,0 +1,11 @@
+#!/bin/bash
+set -euo pipefail
+cd "$GRAFT_REPO_ROOT"
+for M in 0 1 2 4 6; do
+  VSA_EXP_FAST_MODE=$M timeout -k 5 100 python tools/fast_probe.py 300
+done
+for B in 36 54; do
+  VSA_EXP_FS_BAND=$B timeout -k 5 100 python tools/fast_probe.py 300
+done
+timeout -k 5 100 python tools/fast_probe.py 300 1920 1080
+echo PROBE_OK

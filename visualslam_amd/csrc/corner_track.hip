@@ -12,83 +12,24 @@
 //                        raster index) as a 64-bit key, and stores one key per cell (0 = no corner).
 //                        Harris: one wave per rectangle, lane = image column, rows streamed through
 //                        register sliding windows, horizontal neighbours by DPP wave shifts.
-//                        FAST: 256-thread workgroup over LDS-staged tiles.
+//                        FAST: the same layout; the 16 circle pixels come from a register ring of the last
+//                        seven rows and their DPP-shifted copies (fast_cells.hpp).
 //   k_merge_compact      one workgroup marks cells that hold a surviving tracked point, then
 //                        compacts survivors (input order) and new corners (cell raster order)
 //                        with ballot/popcount prefix sums.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "harris_cells.hpp"
+#include "fast_cells.hpp"
 
 
 namespace vsa {
 namespace {
 
-constexpr int TW = 64, TH = 40;         // FAST tile interior (pixels)
-constexpr int HALO = 4;                 // FAST: radius 3 + NMS
-constexpr int PXW = TW + 2 * HALO, PXH = TH + 2 * HALO;
-constexpr int PXS = (PXW + 3 + 3) / 4 * 4;   // LDS row stride of the staged pixels: whole dwords from an aligned column on
-constexpr int SW = TW + 2, SH = TH + 2; // score grid     (interior + 1)
 constexpr uint64_t OCCUPIED = ~0ull;
-
-// i / d for 1 <= d <= 128 and 0 <= i < 64 d (rows of d items, at most 64 rows) through m = fast_div_magic(d): (i * m) >> 22
-// (m * d - 2^22 <= d and i * d < 2^22; i * m < 2^32; tests/test_abi.py checks every case)
-__device__ __forceinline__ uint32_t fast_div_magic(uint32_t d) { return (1u << 22) / d + 1u; }
-__device__ __forceinline__ uint32_t fast_div(uint32_t i, uint32_t m) { return (i * m) >> 22; }
-
-// max / min of 16 values with three-input instructions: 5 + 2 + 1 instead of 15
-__device__ __forceinline__ int max16(const int (&v)[16])
-{
-    const int a = max(max(v[0], v[1]), v[2]), b = max(max(v[3], v[4]), v[5]), c = max(max(v[6], v[7]), v[8]);
-    const int d = max(max(v[9], v[10]), v[11]), e = max(max(v[12], v[13]), v[14]);
-    return max(max(max(a, b), c), max(max(d, e), v[15]));
-}
-__device__ __forceinline__ int min16(const int (&v)[16])
-{
-    const int a = min(min(v[0], v[1]), v[2]), b = min(min(v[3], v[4]), v[5]), c = min(min(v[6], v[7]), v[8]);
-    const int d = min(min(v[9], v[10]), v[11]), e = min(min(v[12], v[13]), v[14]);
-    return min(min(min(a, b), c), min(min(d, e), v[15]));
-}
-
-// FAST-N strength: the largest threshold for which the pixel still passes the segment test, i.e.
-// max over the 16 arcs of N consecutive circle pixels of min(d) (brighter) or min(-d) (darker), minus one; -inf when
-// no arc is uniformly brighter or darker (strength < 0).  Branch-free: arcs are built from 3-pixel minima/maxima
-// (v_min3 / v_max3), every lane does the same ~90 integer operations, so a wave's cost does not depend on whether
-// one of its 64 pixels happens to be a corner.
-template <int N>
-__device__ __forceinline__ float fast_score(const uint8_t *c /* centre in LDS, rows PXS bytes apart */)
-{
-    static_assert(N >= 9 && N <= 12, "FAST-9 .. FAST-12");
-    const int ip = c[0];
-    int d[16];
-    d[0]  = c[-3 * PXS + 0] - ip;  d[1]  = c[-3 * PXS + 1] - ip;
-    d[2]  = c[-2 * PXS + 2] - ip;  d[3]  = c[-1 * PXS + 3] - ip;
-    d[4]  = c[3] - ip;             d[5]  = c[1 * PXS + 3] - ip;
-    d[6]  = c[2 * PXS + 2] - ip;   d[7]  = c[3 * PXS + 1] - ip;
-    d[8]  = c[3 * PXS + 0] - ip;   d[9]  = c[3 * PXS - 1] - ip;
-    d[10] = c[2 * PXS - 2] - ip;   d[11] = c[1 * PXS - 3] - ip;
-    d[12] = c[-3] - ip;            d[13] = c[-1 * PXS - 3] - ip;
-    d[14] = c[-2 * PXS - 2] - ip;  d[15] = c[-3 * PXS - 1] - ip;
-    int lo3[16], hi3[16];          // min / max of circle pixels i, i+1, i+2
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        lo3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
-        hi3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
-    }
-    int lo[16], hi[16];            // min / max over the N consecutive pixels from i
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        lo[i] = min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]);     // 9 consecutive pixels from i
-        hi[i] = max(max(hi3[i], hi3[(i + 3) & 15]), hi3[(i + 6) & 15]);
-        if (N == 10) { lo[i] = min(lo[i], d[(i + 9) & 15]); hi[i] = max(hi[i], d[(i + 9) & 15]); }
-        if (N == 11) { lo[i] = min(min(lo[i], d[(i + 9) & 15]), d[(i + 10) & 15]); hi[i] = max(max(hi[i], d[(i + 9) & 15]), d[(i + 10) & 15]); }
-        if (N == 12) { lo[i] = min(lo[i], lo3[(i + 9) & 15]); hi[i] = max(hi[i], hi3[(i + 9) & 15]); }
-    }
-    const int bright = max16(lo), dark = min16(hi);   // max over arcs of min(d); min over arcs of max(d)
-    const int best = max(max(bright, -dark), 0);
-    return best > 0 ? (float)(best - 1) : -INFINITY;
-}
 
 __global__ __launch_bounds__(64) void k_harris_cells(CornerArgs a)
 {
@@ -98,108 +39,13 @@ __global__ __launch_bounds__(64) void k_harris_cells(CornerArgs a)
 }
 
 
-// ---- FAST: 256-thread workgroup over LDS-staged tiles ------------------------------------------
-// A workgroup owns a rectangle of whole cells (for 18-pixel cells 3 x 2 of them: 54 x 36 pixels) and walks it in tiles of at
-// most TW x TH pixels.  Every pass runs over exactly the items the tile has -- (tw + 8) x (th + 8) staged pixels,
-// (tw + 2) x (th + 2) scores, tw x th candidates -- numbered consecutively and split into row and column by a multiply and a
-// shift (fast_div): walking the full 72 x 48 / 66 x 42 / 64 x 40 frames left a quarter of the lanes idle on 18-pixel cells.
+// ---- FAST: the same shape -- one wave per rectangle of cells, lane = image column (fast_cells.hpp) ----------------
 template <int N>
-__global__ __launch_bounds__(256) void k_fast_cells(CornerArgs a)
+__global__ __launch_bounds__(64) void k_fast_cells(CornerArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // carve: keys | score | pixels
-    const int ncl = a.nbx * a.nby;
-    uint64_t *keys = reinterpret_cast<uint64_t *>(smem);
-    float *sc = reinterpret_cast<float *>(smem + (size_t)((ncl * 8 + 15) & ~15));
-    uint8_t *px = reinterpret_cast<uint8_t *>(sc + SW * SH);
-
-    const int tid = threadIdx.x;
-    // each XCD owns a contiguous band of cell blocks (halo rows/columns are shared inside one L2)
-    const uint32_t item = xcd_contiguous_item(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int bx = (int)(item % gridDim.x), by = (int)(item / gridDim.x);
-    const int rx0 = bx * a.nbx * a.cs, ry0 = by * a.nby * a.cs;
-    const int rw = min(a.nbx * a.cs, a.w - rx0), rh = min(a.nby * a.cs, a.h - ry0);
-    const bool dwords = (((uintptr_t)a.img | a.pitch) & 3u) == 0;   // aligned rows: the tile is fetched as whole dwords
-
-    for (int i = tid; i < ncl; i += 256) keys[i] = 0;
-
-    for (int ty = 0; ty < rh; ty += TH) {
-        for (int tx = 0; tx < rw; tx += TW) {
-            const int tw = min(TW, rw - tx), th = min(TH, rh - ty);
-            const int gx0 = rx0 + tx, gy0 = ry0 + ty;
-            const int pw = tw + 2 * HALO, ph = th + 2 * HALO, gw = tw + 2, gh = th + 2;
-            __syncthreads();  // previous tile fully consumed (also orders the key init)
-
-            // S1: pixels.  Rows and columns outside the image are fetched from clamped addresses: whatever lands there only
-            // feeds scores that are masked off below (a score needs its whole circle inside the image)
-            const int xorg = gx0 - HALO, xa = xorg & ~3, off = dwords ? xorg - xa : 0;
-            if (dwords) {
-                const int nd = (off + pw + 3) >> 2, xmax = (a.w - 1) & ~3;
-                const uint32_t m = fast_div_magic((uint32_t)nd);
-                uint32_t *pxw = reinterpret_cast<uint32_t *>(px);
-                for (int i = tid; i < ph * nd; i += 256) {
-                    const int r = (int)fast_div((uint32_t)i, m), d = i - r * nd;
-                    const int gy = min(max(gy0 - HALO + r, 0), a.h - 1);
-                    const int X = min(max(xa + 4 * d, 0), xmax);
-                    pxw[r * (PXS / 4) + d] = *reinterpret_cast<const uint32_t *>(a.img + (size_t)gy * a.pitch + X);
-                }
-            } else {
-                const uint32_t m = fast_div_magic((uint32_t)pw);
-                for (int i = tid; i < ph * pw; i += 256) {
-                    const int r = (int)fast_div((uint32_t)i, m), c = i - r * pw;
-                    const int gy = min(max(gy0 - HALO + r, 0), a.h - 1);
-                    const int gx = min(max(xorg + c, 0), a.w - 1);
-                    px[r * PXS + c] = a.img[(size_t)gy * a.pitch + gx];
-                }
-            }
-            __syncthreads();
-
-            // S3: score on the (tw+2)x(th+2) grid
-            {
-                const uint32_t m = fast_div_magic((uint32_t)gw);
-                const uint8_t *p0 = px + (HALO - 1) * PXS + off + (HALO - 1);
-                for (int i = tid; i < gw * gh; i += 256) {
-                    const int r = (int)fast_div((uint32_t)i, m), c = i - r * gw;
-                    const int gx = gx0 - 1 + c, gy = gy0 - 1 + r;
-                    float s = -INFINITY;
-                    if (gx >= 3 && gy >= 3 && gx < a.w - 3 && gy < a.h - 3) s = fast_score<N>(p0 + r * PXS + c);
-                    sc[i] = s;
-                }
-            }
-            __syncthreads();
-
-            // S4: threshold, 3x3 NMS with raster tie-break, mask, per-cell maximum
-            {
-                const uint32_t m = fast_div_magic((uint32_t)tw);
-                for (int i0 = 0; i0 < tw * th; i0 += 256) {   // every wave takes part in every ballot
-                    const int i = i0 + tid;
-                    // all nine scores are read unconditionally (from a clamped item for the lanes past the tile's end) and combined
-                    // without short circuits: as a chain of && every neighbour was a branch with an LDS round trip of its own
-                    const int ic = min(i, tw * th - 1);
-                    const int ly = (int)fast_div((uint32_t)ic, m), lx = ic - ly * tw;
-                    const float *q = sc + (ly + 1) * gw + (lx + 1);
-                    const float s = q[0];
-                    const float n0 = q[-gw - 1], n1 = q[-gw], n2 = q[-gw + 1], n3 = q[-1], n4 = q[1], n5 = q[gw - 1], n6 = q[gw], n7 = q[gw + 1];
-                    const bool cand = (i < tw * th) & (s >= a.thr) & (s != -INFINITY) &
-                                      !(n0 >= s) & !(n1 >= s) & !(n2 >= s) & !(n3 >= s) & !(n4 > s) & !(n5 > s) & !(n6 > s) & !(n7 > s);
-                    if (__ballot(cand) == 0ull) continue;  // wave-uniform early out: candidates are sparse
-                    if (cand) {
-                        const int gx = gx0 + lx, gy = gy0 + ly;
-                        if (a.mask && a.mask[(size_t)gy * a.mask_pitch + gx] == 0) continue;
-                        const int cell = ((ty + ly) / a.cs) * a.nbx + (tx + lx) / a.cs;
-                        const uint32_t idx = ((uint32_t)gy << 16) | (uint32_t)gx;
-                        const uint64_t key = ((uint64_t)orderable(s) << 32) | (uint64_t)(~idx);
-                        atomicMax(reinterpret_cast<unsigned long long *>(&keys[cell]), (unsigned long long)key);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < ncl; i += 256) {
-        const int cx = bx * a.nbx + i % a.nbx, cy = by * a.nby + i / a.nbx;
-        if (cx < a.ncx && cy < a.ncy) a.cell_best[(size_t)cy * a.ncx + cx] = keys[i];
-    }
+    VSA_SHORT_KERNEL_PRIORITY();
+    fast_cells_wave<N>(a, blockIdx.x, gridDim.x, smem);
 }
 
 // ---- merge + compaction ---------------------------------------------------------------------
@@ -471,15 +317,13 @@ hipError_t launch_corner_cells(const CornerTrackParams &p, hipStream_t stream)
     if (p.detector == kHarris) {
         hipLaunchKernelGGL(k_harris_cells, dim3(blocks), dim3(64), lds, stream, a);
     } else {
-        cell_block(cs, TW, TH, a.nbx, a.nby);
-        const dim3 grid((a.ncx + a.nbx - 1) / a.nbx, (a.ncy + a.nby - 1) / a.nby);
-        const size_t keys_b = ((size_t)a.nbx * a.nby * 8 + 15) & ~(size_t)15;
-        lds = keys_b + SW * SH * 4 + PXS * PXH;
+        const char *band_env = getenv("VSA_EXP_FS_BAND");      // experiment knob (tools/gpu_r3c.sh)
+        fast_cells_setup(p, a, blocks, lds, band_env ? atoi(band_env) : FS_BAND);
         switch (p.fast_n) {
-        case 9: hipLaunchKernelGGL(k_fast_cells<9>, grid, dim3(256), lds, stream, a); break;
-        case 10: hipLaunchKernelGGL(k_fast_cells<10>, grid, dim3(256), lds, stream, a); break;
-        case 11: hipLaunchKernelGGL(k_fast_cells<11>, grid, dim3(256), lds, stream, a); break;
-        case 12: hipLaunchKernelGGL(k_fast_cells<12>, grid, dim3(256), lds, stream, a); break;
+        case 9: hipLaunchKernelGGL(k_fast_cells<9>, dim3(blocks), dim3(64), lds, stream, a); break;
+        case 10: hipLaunchKernelGGL(k_fast_cells<10>, dim3(blocks), dim3(64), lds, stream, a); break;
+        case 11: hipLaunchKernelGGL(k_fast_cells<11>, dim3(blocks), dim3(64), lds, stream, a); break;
+        case 12: hipLaunchKernelGGL(k_fast_cells<12>, dim3(blocks), dim3(64), lds, stream, a); break;
         default: return hipErrorInvalidValue;
         }
     }

@@ -126,10 +126,10 @@ struct PyrLKParams {
 // otherwise; both produce identical results
 hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream);
 
-// PyrLK and the Harris-track CELL pass of the detector node that follows it in ONE launch (one wave per feature, then one
+// PyrLK and the CELL pass of the detector node (Harris or FAST) that follows it in ONE launch (one wave per feature, then one
 // wave per rectangle of cells, filling the compute units the last PyrLK waves leave idle): the cell pass reads only the
 // image, so only launch_corner_merge(ct) has to follow.  Results are those of launch_pyrlk + launch_corner_cells.
-// pyrlk_cells_fusable(): a Harris detector and 4-byte aligned pyramids.
+// pyrlk_cells_fusable(): 4-byte aligned pyramids (and FAST-9 .. 12).
 bool pyrlk_cells_fusable(const PyrLKParams &lk, const CornerTrackParams &ct);
 hipError_t launch_pyrlk_with_cells(const PyrLKParams &lk, const CornerTrackParams &ct, hipStream_t stream);
 

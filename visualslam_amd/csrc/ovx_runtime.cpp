@@ -864,14 +864,17 @@ vx_status run_node(_vx_node *n, hipStream_t stream)
                                  param<_vx_scalar>(n, 7, VX_TYPE_SCALAR), param<_vx_scalar>(n, 8, VX_TYPE_SCALAR), pyrlk_window(n), &lk);
         if (s != VX_SUCCESS) return s;
         if (_vx_node *h = n->fused_cells) {
-            // the HarrisTrack node that merges this node's output: its cell pass (which reads the image only) rides in this
+            // the HarrisTrack / FastTrack node that merges this node's output: its cell pass (which reads the image only) rides in this
             // launch, with that node's CURRENT parameters; whatever keeps it from doing so leaves the node to run in full
             h->cells_done = false;
             CornerTrackParams ct{};
+            const bool harris = h->kind == K_HARRIS_TRACK;
             if (node_scratch(h) == VX_SUCCESS &&
-                prep_corner_track(kHarris, param<_vx_image>(h, 0, VX_TYPE_IMAGE), param<_vx_array>(h, 1, VX_TYPE_ARRAY),
-                                  param<_vx_image>(h, 2, VX_TYPE_IMAGE), param<_vx_array>(h, 3, VX_TYPE_ARRAY), scalar_f32(h, 4),
-                                  scalar_f32(h, 5), 0u, scalar_u32(h, 6), nullptr, nullptr, h->scratch, h->scratch_size, &ct) == VX_SUCCESS &&
+                prep_corner_track(harris ? kHarris : kFast, param<_vx_image>(h, 0, VX_TYPE_IMAGE), param<_vx_array>(h, 1, VX_TYPE_ARRAY),
+                                  param<_vx_image>(h, 2, VX_TYPE_IMAGE), param<_vx_array>(h, 3, VX_TYPE_ARRAY),
+                                  harris ? scalar_f32(h, 4) : 0.0f, harris ? scalar_f32(h, 5) : (float)scalar_u32(h, 5),
+                                  harris ? 0u : scalar_u32(h, 4), scalar_u32(h, 6), nullptr, nullptr, h->scratch, h->scratch_size,
+                                  &ct) == VX_SUCCESS &&
                 pyrlk_cells_fusable(lk, ct)) {
                 s = hip_status(launch_pyrlk_with_cells(lk, ct, stream));
                 h->cells_done = s == VX_SUCCESS;
@@ -1149,13 +1152,13 @@ vx_status verify_graph(_vx_graph *g)
                 break;
             }
         }
-        // A HarrisTrack node that merges a PyrLK node's output (feature_tracker.cpp:402-422): only its merge pass needs the
+        // A HarrisTrack / FastTrack node that merges a PyrLK node's output (feature_tracker.cpp:402-430): only its merge pass needs the
         // tracked points; its cell pass reads the image and the mask, which are ready when PyrLK starts if no node from the
         // PyrLK node up to the HarrisTrack node writes them.  The cell pass then runs inside the PyrLK launch, whose last
         // waves otherwise leave compute units idle, and the frame has one launch less.
         for (size_t hi = 0; hi < n && getenv("VISUALSLAM_AMD_NO_FUSION") == nullptr; ++hi) {
             _vx_node *ht = g->nodes[hi];
-            if (ht->kind != K_HARRIS_TRACK) continue;
+            if (ht->kind != K_HARRIS_TRACK && ht->kind != K_FAST_TRACK) continue;
             auto *tracked = param<_vx_array>(ht, 3, VX_TYPE_ARRAY);
             if (!tracked) continue;
             for (size_t li = 0; li < n; ++li) {

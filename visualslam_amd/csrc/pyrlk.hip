@@ -32,6 +32,7 @@
 
 #include "kernels.hpp"
 #include "harris_cells.hpp"
+#include "fast_cells.hpp"
 
 namespace vsa {
 namespace {
@@ -606,10 +607,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(VSA_LK_VGPR_HALF
     pyrlk_wave<NSEG, WMAX, ALIGNED, FULL>(a, blockIdx.x, smem);
 }
 
-// PyrLK + the Harris-track cell pass in one launch (launch_pyrlk_with_cells): workgroups [0, a.capacity) each track a feature,
-// the rest each own a rectangle of detector cells (harris_cells.hpp).  PyrLK's waves come first -- they are the long ones,
-// and a launch of them alone ends with compute units idling behind its slowest waves; the cell-pass waves fill that tail.
-template <int NSEG, int WMAX, bool FULL>
+// PyrLK + the detector's cell pass in one launch (launch_pyrlk_with_cells): workgroups [0, a.capacity) each track a feature,
+// the rest each own a rectangle of detector cells (harris_cells.hpp, fast_cells.hpp).  PyrLK's waves come first -- they are the
+// long ones, and a launch of them alone ends with compute units idling behind its slowest waves; the cell-pass waves fill that tail.
+// DET: 0 = Harris, 9 .. 12 = FAST-N.
+template <int NSEG, int WMAX, bool FULL, int DET>
 __device__ __forceinline__ void pyrlk_cells_wave(const LKArgs &a, const CornerArgs &c)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -618,24 +620,43 @@ __device__ __forceinline__ void pyrlk_cells_wave(const LKArgs &a, const CornerAr
         // the cell-pass waves start in the launch's tail, beside PyrLK's slowest waves: with issue priority over them the
         // launch alone ends 2.4 us earlier (40.5 against 42.9 us); the other order (cell pass first) changes nothing
         __builtin_amdgcn_s_setprio(3);
-        harris_cells_wave(c, blockIdx.x - a.capacity, gridDim.x - a.capacity, reinterpret_cast<uint8_t *>(smem));
+        if constexpr (DET == 0) harris_cells_wave(c, blockIdx.x - a.capacity, gridDim.x - a.capacity, reinterpret_cast<uint8_t *>(smem));
+        else fast_cells_wave<DET>(c, blockIdx.x - a.capacity, gridDim.x - a.capacity, reinterpret_cast<uint8_t *>(smem));
     }
 }
-template <int NSEG, int WMAX, bool FULL>
+template <int NSEG, int WMAX, bool FULL, int DET>
 __global__ __launch_bounds__(64) void k_pyrlk_cells(LKArgs a, CornerArgs c)
 {
-    pyrlk_cells_wave<NSEG, WMAX, FULL>(a, c);
+    pyrlk_cells_wave<NSEG, WMAX, FULL, DET>(a, c);
 }
-template <int NSEG, int WMAX, bool FULL>
+template <int NSEG, int WMAX, bool FULL, int DET>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(VSA_LK_VGPR_HALF))) void k_pyrlk_cells_104(LKArgs a, CornerArgs c)
 {
     VSA_LK_PIN_104();
-    pyrlk_cells_wave<NSEG, WMAX, FULL>(a, c);
+    pyrlk_cells_wave<NSEG, WMAX, FULL, DET>(a, c);
+}
+
+template <int NSEG, int WMAX, bool FULL, int DET>
+void launch_cells_kernel(const LKArgs &a, const CornerArgs &c, dim3 grid, size_t lds, hipStream_t stream)
+{
+    if constexpr (NSEG == 7) hipLaunchKernelGGL((k_pyrlk_cells_104<NSEG, WMAX, FULL, DET>), grid, dim3(64), lds, stream, a, c);
+    else hipLaunchKernelGGL((k_pyrlk_cells<NSEG, WMAX, FULL, DET>), grid, dim3(64), lds, stream, a, c);
+}
+template <int NSEG, int WMAX, bool FULL>
+void launch_cells_detector(const LKArgs &a, const CornerArgs &c, int det, dim3 grid, size_t lds, hipStream_t stream)
+{
+    switch (det) {
+    case 0: launch_cells_kernel<NSEG, WMAX, FULL, 0>(a, c, grid, lds, stream); break;
+    case 9: launch_cells_kernel<NSEG, WMAX, FULL, 9>(a, c, grid, lds, stream); break;
+    case 10: launch_cells_kernel<NSEG, WMAX, FULL, 10>(a, c, grid, lds, stream); break;
+    case 11: launch_cells_kernel<NSEG, WMAX, FULL, 11>(a, c, grid, lds, stream); break;
+    default: launch_cells_kernel<NSEG, WMAX, FULL, 12>(a, c, grid, lds, stream); break;
+    }
 }
 
 template <int NSEG, int WMAX>
 hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipStream_t stream, const CornerArgs *cells = nullptr,
-                         uint32_t cell_blocks = 0, size_t cell_lds = 0)
+                         uint32_t cell_blocks = 0, size_t cell_lds = 0, int det = 0)
 {
     using G = LKTiles<WMAX>;
     constexpr int PS = G::PS, PFLOATS = G::PFLOATS, JFLOATS = G::JFLOATS;
@@ -649,13 +670,8 @@ hipError_t launch_bucket(const LKArgs &a, bool aligned, uint32_t capacity, hipSt
     if (cells) {   // aligned pyramids only (pyrlk_cells_fusable)
         const dim3 grid(capacity + cell_blocks);
         const size_t both = lds > cell_lds ? lds : cell_lds;
-        if constexpr (NSEG == 7) {
-            if (full) hipLaunchKernelGGL((k_pyrlk_cells_104<NSEG, WMAX, true>), grid, block, both, stream, a, *cells);
-            else hipLaunchKernelGGL((k_pyrlk_cells_104<NSEG, WMAX, false>), grid, block, both, stream, a, *cells);
-        } else {
-            if (full) hipLaunchKernelGGL((k_pyrlk_cells<NSEG, WMAX, true>), grid, block, both, stream, a, *cells);
-            else hipLaunchKernelGGL((k_pyrlk_cells<NSEG, WMAX, false>), grid, block, both, stream, a, *cells);
-        }
+        if (full) launch_cells_detector<NSEG, WMAX, true>(a, *cells, det, grid, both, stream);
+        else launch_cells_detector<NSEG, WMAX, false>(a, *cells, det, grid, both, stream);
         return hipGetLastError();
     }
     const dim3 grid(capacity);
@@ -682,7 +698,7 @@ bool pyramids_aligned(const PyrLKParams &p)
     return aligned;
 }
 
-hipError_t launch_lk(const PyrLKParams &p, hipStream_t stream, const CornerArgs *cells, uint32_t cell_blocks, size_t cell_lds)
+hipError_t launch_lk(const PyrLKParams &p, hipStream_t stream, const CornerArgs *cells, uint32_t cell_blocks, size_t cell_lds, int det)
 {
     const bool aligned = pyramids_aligned(p);
     LKArgs a{};
@@ -701,11 +717,11 @@ hipError_t launch_lk(const PyrLKParams &p, hipStream_t stream, const CornerArgs 
     a.segs = (win + a.seglen - 1) / a.seglen;
     a.lanes = a.segs * win;
 
-    if (win <= 8) return launch_bucket<1, 8>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);   // one pixel per lane
-    if (win <= 10) return launch_bucket<2, 10>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
-    if (win <= 16) return launch_bucket<4, 16>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
-    if (win <= 21) return launch_bucket<7, 21>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
-    return launch_bucket<16, 32>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds);
+    if (win <= 8) return launch_bucket<1, 8>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds, det);   // one pixel per lane
+    if (win <= 10) return launch_bucket<2, 10>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds, det);
+    if (win <= 16) return launch_bucket<4, 16>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds, det);
+    if (win <= 21) return launch_bucket<7, 21>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds, det);
+    return launch_bucket<16, 32>(a, aligned, p.capacity, stream, cells, cell_blocks, cell_lds, det);
 }
 
 }  // namespace
@@ -713,12 +729,13 @@ hipError_t launch_lk(const PyrLKParams &p, hipStream_t stream, const CornerArgs 
 hipError_t launch_pyrlk(const PyrLKParams &p, hipStream_t stream)
 {
     if (p.capacity == 0) return hipSuccess;
-    return launch_lk(p, stream, nullptr, 0, 0);
+    return launch_lk(p, stream, nullptr, 0, 0, 0);
 }
 
 bool pyrlk_cells_fusable(const PyrLKParams &lk, const CornerTrackParams &ct)
 {
-    return ct.detector == kHarris && ct.cell_size != 0u && ct.image.width <= 65535u && ct.image.height <= 65535u &&
+    const bool det_ok = ct.detector == kHarris || (ct.detector == kFast && ct.fast_n >= 9u && ct.fast_n <= 12u);
+    return det_ok && ct.cell_size != 0u && ct.image.width <= 65535u && ct.image.height <= 65535u &&
            lk.capacity != 0u && pyramids_aligned(lk);
 }
 
@@ -728,8 +745,9 @@ hipError_t launch_pyrlk_with_cells(const PyrLKParams &lk, const CornerTrackParam
     CornerArgs c{};
     uint32_t blocks = 0;
     size_t lds = 0;
-    harris_cells_setup(ct, c, blocks, lds, HS_BAND_FUSED);
-    return launch_lk(lk, stream, &c, blocks, lds);
+    if (ct.detector == kHarris) harris_cells_setup(ct, c, blocks, lds, HS_BAND_FUSED);
+    else fast_cells_setup(ct, c, blocks, lds, FS_BAND_FUSED);
+    return launch_lk(lk, stream, &c, blocks, lds, ct.detector == kHarris ? 0 : (int)ct.fast_n);
 }
 
 }  // namespace vsa
