@@ -167,10 +167,10 @@ def load_profile_json(name):
 
 def profiled_launch_ms(kernel):
     """average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of a single-stream run of this bench
-    (profiles/r02_single_stream_kernel_stats.csv): the kernel's own begin-to-end time, without the few microseconds of dispatch
+    (profiles/r03_single_stream_kernel_stats.csv): the kernel's own begin-to-end time, without the few microseconds of dispatch
     latency that the HIP events around a launch include"""
     import csv
-    path = os.path.join(ROOT, "profiles", "r02_single_stream_kernel_stats.csv")
+    path = os.path.join(ROOT, "profiles", "r03_single_stream_kernel_stats.csv")
     if not os.path.exists(path):
         return None
     want = kernel.replace(" ", "")
@@ -537,7 +537,7 @@ def main():
             "frame_algorithmic_frac_of_hbm_peak": bytes_frame * fps / 1e9 / (HBM_PEAK_GBS * world),
             # the dominant kernel against the HBM roof.  launch_ms: the kernel ALONE (stream 0 driven by itself after the
             # timed region, HIP events, 50 launches); launch_ms_in_timed_region: the same events while the other streams'
-            # kernels share the GPU (mean concurrency ~2.3, profiles/r02_bench_concurrency.txt) -- longer, not slower work
+            # kernels share the GPU (mean concurrency ~2.3, profiles/r03_bench_concurrency.txt) -- longer, not slower work
             "roofline": {"kernel": f"{lk_name} ({lk_what}, {cfg['capacity']} points x {cfg['levels']} levels, {cfg['win']}x{cfg['win']})",
                          "bound": "hbm", "achieved": lk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lk_gbs / HBM_PEAK_GBS,
                          "traffic": lk_counters.get("hbm_bytes"), "launch_ms": lk_alone_ms,

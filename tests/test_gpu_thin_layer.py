@@ -285,9 +285,15 @@ def test_pyrlk_windows_bit_exact(gpu, win):
     ref = O.optical_flow_pyr_lk(p0, p1, pts, None, O.TERM_BOTH, 0.01, 5, win, sum_mode=O.SUM_F64SEQ)
     np.testing.assert_array_equal(ref[:, 0] >= 0, tracked)
     d = np.abs(got[tracked] - ref[tracked]).max(axis=1)
-    # 3x3 windows are ill-conditioned: the summation order can flip one |eta| < eps stop decision, which moves a
-    # point by up to one more step (< eps = 0.01); everything else agrees to 1e-3 px
-    assert d.max() <= (0.01 if win > 3 else 0.02) and np.quantile(d, 0.99) <= 0.001
+    # north_star's bar: 0.01 px.  Met by every point for windows >= 5.  3 x 3 windows are ill-conditioned: the summation order
+    # can flip one |eta| < eps stop decision, which moves a point by one more step (< eps = 0.01 px on top of agreement to
+    # 1e-3): on this case 1 of the 472 tracked points (0.2 %) lands at 0.0104 px.  Asserted as exactly that: at most 0.5 % of
+    # the points beyond 0.01 px, none beyond 0.011 px.
+    if win > 3:
+        assert d.max() <= 0.01
+    else:
+        assert (d > 0.01).mean() <= 0.005 and d.max() <= 0.011
+    assert np.quantile(d, 0.99) <= 0.001
 
 
 @pytest.mark.parametrize("levels,term,iters", [(1, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 5), (6, nvxcu.NVXCU_TERM_CRITERIA_BOTH, 5),
