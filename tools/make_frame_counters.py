@@ -8,12 +8,23 @@ this GPU (tools/calib_fetch.hip, profiles/r01_fetch_calibration.txt): coalesced 
 (rows of 8-9 dwords at random positions) are counted as whole 128-byte lines, x1.  So hbm_bytes = FETCH x1 + WRITE for the tile-gather
 kernels (k_pyrlk*, also with the Harris cell pass fused in, and the merge) and FETCH x2 + WRITE for the streaming ones (colour convert,
 pyramid, the Harris cell pass alone); both readings are kept.
-usage: make_frame_counters.py <pmc_summary.txt> <out.json>"""
+The stamp is the commit the kernels were built from: the script refuses to write one while visualslam_amd/csrc has uncommitted changes, and
+`--check <frame_counters.json>` fails when the kernel sources have changed between the stamped commit and HEAD (profiles older than the code).
+usage: make_frame_counters.py <pmc_summary.txt> <out.json>      |      make_frame_counters.py --check <frame_counters.json>"""
 import collections
 import json
 import re
 import subprocess
 import sys
+
+if len(sys.argv) == 3 and sys.argv[1] == "--check":
+    stamp = json.load(open(sys.argv[2]))["commit"]
+    if "+" in stamp or subprocess.run(["git", "diff", "--quiet", stamp, "HEAD", "--", "visualslam_amd/csrc"]).returncode != 0:
+        sys.exit(f"profiles stamped {stamp} do not describe the kernels at HEAD: regenerate them (tools/gpu_profile_r3*.sh)")
+    if subprocess.run(["git", "status", "--porcelain", "visualslam_amd/csrc"], capture_output=True, text=True).stdout.strip():
+        sys.exit("visualslam_amd/csrc has uncommitted changes: the committed profiles do not describe this tree")
+    print(f"profiles stamped {stamp}: kernel sources unchanged since")
+    sys.exit(0)
 
 rows = collections.defaultdict(dict)
 calls = collections.defaultdict(int)
@@ -24,9 +35,10 @@ for ln in open(sys.argv[1]):
         calls[m.group(1).strip()] = max(calls[m.group(1).strip()], int(m.group(3)))
 per_frame = {k for k, n in calls.items() if 2 * n >= max(calls.values())}    # the others ran once, in the tracker's first-frame set-up
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-dirty = bool(subprocess.run(["git", "status", "--porcelain", "visualslam_amd/csrc"], capture_output=True, text=True).stdout.strip())
-out = {"commit": commit + ("+uncommitted kernel changes" if dirty else ""),
-       "source": "tools/gpu_profile2.sh: rocprofv3 --pmc passes over tools/prof_kernels.py graph (one camera stream, 1080p / 5 levels / 4096 points / 21x21)",
+if subprocess.run(["git", "status", "--porcelain", "visualslam_amd/csrc"], capture_output=True, text=True).stdout.strip():
+    sys.exit("visualslam_amd/csrc has uncommitted changes: commit the kernels the profile was measured on before stamping it")
+out = {"commit": commit,
+       "source": "tools/gpu_profile_r3a.sh: rocprofv3 --pmc passes over tools/prof_kernels.py graph (one camera stream, 1080p / 5 levels / 4096 points / 21x21)",
        "peak_wave_instructions_per_ns": 989.0,
        "peak_note": "f32 FMA issue rate measured on this GPU with all SIMDs busy (profiles/r01_valu_issue_rates.txt): one wave-instruction per 1.035 ns per SIMD x 1024 SIMDs",
        "by_kernel": {}}

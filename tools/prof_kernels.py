@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run one primitive of the 1080p workload repeatedly (for rocprofv3 --kernel-trace / --pmc passes).
-usage: prof_kernels.py {lk|harris|pyramid|cvt|frame|graph} [reps]
+usage: prof_kernels.py {lk|harris|pyramid|cvt|frame|graph} [reps] [c2|c3]      (c3: the 4K / 7 levels / FAST-9 / 10 k features workload)
   frame: whole frames through the thin layer (five launches: nvxcu primitives cannot fuse)
   graph: whole frames of ONE camera stream through the OpenVX graph as bench.py builds it (the fused launches)"""
 import os
@@ -19,6 +19,9 @@ what = sys.argv[1] if len(sys.argv) > 1 else "lk"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 W, H = 1920, 1080
 p = Params(pyr_levels=5, lk_win_size=21, array_capacity=4096)
+if len(sys.argv) > 3 and sys.argv[3] == "c3":
+    W, H = 3840, 2160
+    p = Params(pyr_levels=7, lk_win_size=21, array_capacity=10000, use_harris_detector=False, fast_type=9, fast_thresh=25)
 base = synth.base_frame(W, H, 1234)
 if what == "graph":
     from visualslam_amd import ovx
