@@ -3,6 +3,8 @@
 // Part of the OpenVX-subset runtime (ovx_internal.hpp).
 #include "ovx_internal.hpp"
 
+#include <sched.h>
+
 namespace ovxrt {
 
 using namespace vsa;
@@ -396,11 +398,25 @@ void update_perf(vx_perf_t *p, uint64_t ns)
     p->max = ns > p->max ? ns : p->max;
 }
 
+// How a host thread waits for its graph's stream.  hipStreamSynchronize spins on the completion signal without ever giving up
+// its core: fine with a core per camera-stream thread, but with more such threads than cores the ones that hold a core spin
+// through their whole time slice while the others' finished frames wait milliseconds to be noticed (a 20-frame run of 32 streams
+// on 16 cores: threads starting up to 14 ms late, streams finishing 10 ms apart -- tools/exp_r3_cold.sh).
+// VISUALSLAM_AMD_YIELD_SYNC=1 polls instead and offers the core to any other runnable thread between two polls.
+static hipError_t wait_for_stream(hipStream_t stream)
+{
+    static const bool yield_sync = [] { const char *e = getenv("VISUALSLAM_AMD_YIELD_SYNC"); return e && e[0] == '1'; }();
+    if (!yield_sync) return hipStreamSynchronize(stream);
+    hipError_t e;
+    while ((e = hipStreamQuery(stream)) == hipErrorNotReady) sched_yield();
+    return e;
+}
+
 // Drains the graph's stream and brings the host's view (array counts, num_corners scalars, matrix values) up to date
 // with what the kernels enqueued so far have written.  Called before every host (user-kernel) node and at the end.
 vx_status sync_host_view(_vx_graph *g)
 {
-    if (hipStreamSynchronize(g->stream) != hipSuccess) { g->state = VX_GRAPH_STATE_ABANDONED; return VX_FAILURE; }
+    if (wait_for_stream(g->stream) != hipSuccess) { g->state = VX_GRAPH_STATE_ABANDONED; return VX_FAILURE; }
     walk_mirrors(g,
         [](_vx_array *a, uint32_t *slot) {
             if (!a->mirror_pending) return;
