@@ -52,16 +52,17 @@ CONFIGS = {
 }
 
 
-def lk_kernel_names(win):
+def lk_kernel_names(win, det=0):
     """(PyrLK alone, PyrLK + detector cell pass): the instantiations pyrlk.hip's launch_lk / launch_bucket pick for this window on
-    4-byte-aligned pyramids -- the same bucket and lane-map arithmetic, so the bench line names the kernel that ran"""
+    4-byte-aligned pyramids -- the same bucket and lane-map arithmetic, so the bench line names the kernel that ran.
+    det: 0 = Harris cell pass, 9 .. 12 = FAST-N (the last template argument of the fused kernel)"""
     segs = max(1, min(64 // win, win))
     seglen = (win + segs - 1) // segs
     segs = (win + seglen - 1) // seglen
     nseg, wmax = next(b for b in ((1, 8), (2, 10), (4, 16), (7, 21), (16, 32)) if win <= b[1])
     full = "true" if seglen == nseg and segs * seglen == win else "false"
     cap = "_104" if nseg == 7 else ""
-    return f"k_pyrlk{cap}<{nseg},{wmax},true,{full}>", f"k_pyrlk_cells{cap}<{nseg},{wmax},{full}>"
+    return f"k_pyrlk{cap}<{nseg},{wmax},true,{full}>", f"k_pyrlk_cells{cap}<{nseg},{wmax},{full},{det}>"
 
 
 def metric_name(config, homography):
@@ -505,15 +506,15 @@ def main():
         bytes_frame = B["pyramid"] + B["detect"] + B["lk"] + B["cvt"]
         frames = args.steps * args.streams * world
         fps = frames / elapsed
-        # The OpenVX graph runs the HarrisTrack node's cell pass inside the PyrLK launch (vxVerifyGraph's node fusion): the dominant
+        # The OpenVX graph runs the HarrisTrack / FastTrack node's cell pass inside the PyrLK launch (vxVerifyGraph's node fusion): the dominant
         # kernel is then PyrLK + cell pass, and its algorithmic bytes are PyrLK's plus the detector's read of level 0
-        lk_alone_name, lk_cells_name = lk_kernel_names(cfg["win"])
-        fused = args.api == "ovx" and cfg["harris"] and "VISUALSLAM_AMD_NO_FUSION" not in os.environ
+        lk_alone_name, lk_cells_name = lk_kernel_names(cfg["win"], 0 if cfg["harris"] else 9)
+        fused = args.api == "ovx" and "VISUALSLAM_AMD_NO_FUSION" not in os.environ
         lk_bytes = B["lk"] + (W * H if fused else 0)
         lk_name = lk_cells_name if fused else lk_alone_name
-        lk_what = "PyrLK + HarrisTrack cell pass" if fused else "PyrLK"
+        lk_what = ("PyrLK + HarrisTrack cell pass" if cfg["harris"] else "PyrLK + FastTrack cell pass") if fused else "PyrLK"
         lk_gbs = lk_bytes / (max(lk_alone_ms, 1e-9) * 1e-3) / 1e9
-        counters = load_profile_json("frame_counters.json") if args.config == "c2" and not args.homography and fused else None
+        counters = load_profile_json("frame_counters.json") if args.config == "c2" and not args.homography and fused and cfg["harris"] else None
         lk_counters = (counters or {}).get("by_kernel", {}).get("k_pyrlk", {})
         out = {
             "metric": metric_name(args.config, args.homography),
