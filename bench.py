@@ -271,6 +271,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=-1,
                     help="after the timed block, repeat it this many times for repeat_frames_per_s (default: 15, fewer when a block is long)")
+    ap.add_argument("--preheat-s", type=float, default=0.5,
+                    help="untimed run of the same workload before the warm-up steps, this many seconds: brings the GPU from its idle clock "
+                         "to its operating clocks (5 warm-up steps are 1.3 ms; the ramp takes ~50 ms). 0 = none")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="--gpus N without a launcher: end the ranks after this many seconds")
     ap.add_argument("--pg-timeout", type=float, default=120.0, help="process-group timeout in seconds (a rank that never arrives is an error)")
     ap.add_argument("--dry-run", action="store_true",
@@ -301,7 +304,9 @@ def main():
     if args.dry_run:
         dev = rank_device(local_rank, args.dry_run_devices or args.gpus)
         print(json.dumps({"rank": rank, "world": world, "device": dev, "streams": my_streams, "phases": phases,
-                          "host_cores": cores, "host_threads_total": len(my_streams) * world}), flush=True)
+                          "preheat": {"seconds": args.preheat_s, "steps": preheat_steps,
+                        "note": "untimed set-up run of the same workload so that the GPU is at its operating clocks; the W warm-up steps follow"},
+            "host_cores": cores, "host_threads_total": len(my_streams) * world}), flush=True)
         return
 
     import numpy as np
@@ -431,7 +436,19 @@ def main():
             for k in range(k0, k0 + n):
                 step(k)
 
-    run(0, args.warmup)
+    # A GPU that has been idle sits at its lowest clock (rocm-smi: sclk 534 MHz) and takes tens of milliseconds of load to reach its
+    # operating point; W = 5 warm-up steps are over after 1.3 ms (profiles/r03_kernel_experiments.txt).  The same workload is therefore run
+    # untimed for --preheat-s seconds first -- set-up, like building the graphs -- and the W warm-up steps and K timed steps follow at once.
+    k_at = 0
+    preheat_steps = 0
+    t_pre = time.perf_counter()
+    while args.preheat_s > 0 and time.perf_counter() - t_pre < args.preheat_s:
+        run(k_at, 25)
+        torch.cuda.synchronize()
+        k_at += 25
+        preheat_steps += 25
+    run(k_at, args.warmup)
+    k_at += args.warmup
     torch.cuda.synchronize()
     if args.api == "ovx":
         # HIP events around the PyrLK node of stream 0 only (two event records per frame on that graph's stream)
@@ -442,7 +459,7 @@ def main():
         trackers[0].lk_events = []
     barrier(world)
     t0 = time.perf_counter()
-    run(args.warmup, args.steps)
+    run(k_at, args.steps)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier(world)
@@ -467,7 +484,7 @@ def main():
     # from block to block, so one block alone cannot show a regression of a few percent.
     n_rep = args.repeats if args.repeats >= 0 else max(3, min(15, int(8.0 / max(elapsed, 1e-3))))
     rep_fps = []
-    k_next = args.warmup + args.steps
+    k_next = k_at + args.steps
     for _ in range(n_rep):
         barrier(world)
         r0 = time.perf_counter()
@@ -531,6 +548,8 @@ def main():
             "repeat_frames_per_s": ({"median": float(np.median(rep_fps)), "min": min(rep_fps), "max": max(rep_fps), "blocks": len(rep_fps),
                                      "note": "the timed block run again back to back (same steps, barriers and synchronisation); "
                                              "value / ms_per_step are the first block's"} if rep_fps else None),
+            "preheat": {"seconds": args.preheat_s, "steps": preheat_steps,
+                        "note": "untimed set-up run of the same workload so that the GPU is at its operating clocks; the W warm-up steps follow"},
             "host_cores": cores, "host_threads_total": args.streams * world if (args.api == "ovx" and args.host_threads) else world,
             "tracks_per_sec": fps * float(np.mean(n_tracks)),
             "points_per_frame": float(np.mean(n_points)), "tracked_per_frame": float(np.mean(n_tracks)),
