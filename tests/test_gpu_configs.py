@@ -149,6 +149,57 @@ def test_config4_1080p_graph_with_homography_node(ctx):
         assert cw > 0.9 * (cur[:, 0] >= 0).sum()
 
 
+def test_config4_homography_graphs_of_many_streams_at_once(ctx):
+    """configs[4] under contention: 12 camera streams (own graph and HIP stream each, a Python thread per stream: ctypes drops
+    the GIL across vxProcessGraph) run the tracker graph with the FindHomography node for 10 frames at the same time; EVERY
+    frame's H and inlier mask of every stream is the oracle's.  The hypothesis workgroups of one launch sit on different XCDs and
+    hand their results to the refining workgroup past the L2s (homography.hip): a stale read would pick another hypothesis."""
+    import threading
+    w, h, n_streams, n_frames, ring_len = 800, 600, 12, 10, 5
+    p = Params(pyr_levels=4, lk_num_iters=5, lk_win_size=21, array_capacity=2000, detector_cell_size=18,
+               use_harris_detector=True, harris_k=0.04, harris_thresh=100.0)
+    base = synth.base_frame(w, h, 777)
+    frames = [synth.to_rgbx(synth.gray_frame(base, t, 777)) for t in range(ring_len)]
+    ring = _ring(ctx, frames)
+    phases = [s % ring_len for s in range(n_streams)]
+    trackers = [VxFeatureTracker(ctx, p, w, h, ring[ph], None, homography=True, homography_first=bool(s & 1)) for s, ph in enumerate(phases)]
+    got = [[] for _ in range(n_streams)]
+    errors = []
+    start = threading.Barrier(n_streams)
+
+    def run(s):
+        try:
+            start.wait()
+            for k in range(n_frames):
+                trackers[s].track(ring[(phases[s] + 1 + k) % ring_len], None)
+                Hg, mg = trackers[s].homography()
+                got[s].append((Hg.copy(), mg.copy(), trackers[s].merged().copy()))
+        except Exception as e:      # noqa: BLE001
+            errors.append((s, repr(e)))
+
+    ths = [threading.Thread(target=run, args=(s,)) for s in range(n_streams)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    want = {}
+    for ph in sorted(set(phases)):
+        ref = OracleTracker(p, omp=True)
+        ref.init(frames[ph], None)
+        seq = []
+        for k in range(n_frames):
+            old, cur = ref.track(frames[(ph + 1 + k) % ring_len], None)
+            Hw, mw, _ = O.find_homography(old, cur, 3.0, 2000, 10, 0.995, 0.45)
+            seq.append((Hw, mw, ref.prev_pts.copy()))
+        want[ph] = seq
+    for s, ph in enumerate(phases):
+        for k in range(n_frames):
+            assert got[s][k][0].tobytes() == want[ph][k][0].tobytes(), f"stream {s} frame {k}: H"
+            assert got[s][k][1].tobytes() == want[ph][k][1].tobytes(), f"stream {s} frame {k}: inlier mask"
+            assert got[s][k][2].tobytes() == want[ph][k][2].tobytes(), f"stream {s} frame {k}: merged features"
+
+
 def test_config2_4k_fast_graph(ctx):
     """configs[2] as one graph: 3840x2160, 7 levels, FAST-9 (threshold 25) track, 10 000 features, 21x21 PyrLK"""
     w, h = 3840, 2160

@@ -506,6 +506,51 @@ def test_fast_cell_pass_in_the_pyrlk_launch_or_not(gpu, monkeypatch, fast_n, win
         assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
 
 
+@pytest.mark.parametrize("harris,cap", [(True, 1500), (False, 1500), (True, 5000)])
+@pytest.mark.parametrize("homography_first", [False, True])
+@pytest.mark.parametrize("fusion", [True, False])
+def test_detector_merge_pass_in_the_find_homography_launch_or_not(gpu, monkeypatch, harris, cap, homography_first, fusion):
+    """A FindHomography node on the PyrLK matches (stabilizer.cpp:264-273) and the detector node's merge pass share one launch,
+    led by whichever node comes first in the order -- the stabilizer creates the homography node first (:266,299), bench.py's
+    configs[4] graph the detector.  Fused or apart, every frame's features, H and inlier mask are the oracle's bit for bit.
+    Capacity 5000 takes the homography kernel's any-size form (the capacities allow more than 16 points per thread)."""
+    if not fusion:
+        monkeypatch.setenv("VISUALSLAM_AMD_NO_FUSION", "1")
+    c = L.vxCreateContext()
+    assert L.vxGetStatus(c) == ovx.VX_SUCCESS
+    try:
+        w, h = 643, 481
+        p = Params(pyr_levels=4, lk_win_size=21, use_harris_detector=harris, harris_thresh=500.0, fast_type=9, fast_thresh=15,
+                   array_capacity=cap)
+        frames = _frames(w, h, 4, seed=91 + cap)
+        imgs = []
+        for f in frames:
+            img = L.vxCreateImage(c, w, h, ovx.VX_DF_IMAGE_RGBX)
+            ovx.write_image(img, f)
+            imgs.append(img)
+        trk = VxFeatureTracker(c, p, w, h, imgs[0], None, homography=True, homography_first=homography_first)
+        f = ovx.graph_fusions(trk.g)
+        assert f["merge_in_homography"] == (1 if fusion else 0) and f["cells_in_pyrlk"] == (1 if fusion else 0)
+        buf = (C.c_int * 8)()
+        order = list(buf[:L.visualslam_amd_graph_order(trk.g, buf, 8)])
+        assert (order.index(ovx.K_FIND_HOMOGRAPHY) < order.index(ovx.K_HARRIS_TRACK if harris else ovx.K_FAST_TRACK)) == homography_first
+        ref = OracleTracker(p)
+        ref.init(frames[0], None)
+        for t in range(1, len(frames)):
+            trk.track(imgs[t], None)
+            old, cur = ref.track(frames[t], None)
+            assert trk.prev().tobytes() == old.tobytes(), f"frame {t}: previous features"
+            assert trk.curr().tobytes() == cur.tobytes(), f"frame {t}: tracked features"
+            assert trk.merged().tobytes() == ref.prev_pts.tobytes(), f"frame {t}: merged features"
+            Hw, mw, cw = O.find_homography(old, cur, 3.0, 2000, 10, 0.995, 0.45)
+            Hg, mg = trk.homography()
+            assert Hg.tobytes() == Hw.tobytes(), f"frame {t}: H"
+            assert mg.tobytes() == mw.tobytes(), f"frame {t}: inlier mask"
+            assert cw > 0
+    finally:
+        assert L.vxReleaseContext(C.byref(C.c_void_p(c))) == ovx.VX_SUCCESS
+
+
 def test_cell_pass_is_not_fused_when_its_image_is_written_after_pyrlk_starts(ctx):
     """the detector reads a copy of the grey frame made by a node that runs between PyrLK and the detector: the cell pass must
     wait for it (run fused, it would see the previous frame's copy)"""
@@ -560,8 +605,8 @@ def test_sfm_front_end_graph_matches_oracle(gpu, monkeypatch, use_mask, fusion):
             ovx.write_image(mask, mask_np)
         trk = VxSfmFrontEnd(c, p, w, h, imgs[0], mask)
         fz = ovx.graph_fusions(trk.g)
-        assert fz == ({"color_convert_in_pyramid": 1, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 1} if fusion else
-                      {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 0, "virtual_gray_is_level0": 0})
+        assert fz == ({"color_convert_in_pyramid": 1, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 1, "merge_in_homography": 0} if fusion else
+                      {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 0, "virtual_gray_is_level0": 0, "merge_in_homography": 0})
         ref = OracleTracker(p)
         ref.init(frames[0], mask_np)
         np.testing.assert_array_equal(trk.merged(), ref.prev_pts)

@@ -433,6 +433,40 @@ def test_tracker_graph_feeding_homography_orders_after_lk(ctx):
     order = _order(ft["g"])
     assert order.index(ovx.K_FIND_HOMOGRAPHY) > order.index(ovx.K_PYRLK)
     assert order[:3] == [ovx.K_COLOR_CONVERT, ovx.K_GAUSSIAN_PYRAMID, ovx.K_PYRLK]
+    # the detector node's merge pass and the homography share a launch: both only read what PyrLK wrote
+    assert ovx.graph_fusions(ft["g"])["merge_in_homography"] == 1
+
+
+def test_homography_and_merge_share_a_launch_only_when_the_later_node_can_move_up(ctx, monkeypatch):
+    """vxVerifyGraph pairs a FindHomography node with the detector node whose cell pass rides in the PyrLK launch (the merge
+    pass is all that is left of it): whichever comes first in the order launches for both.  No pair when the detector's cell
+    pass could not be moved into the PyrLK launch (here: a node after PyrLK writes the detector's mask), and none with
+    VISUALSLAM_AMD_NO_FUSION."""
+    def graph(mask_written_late):
+        ft = _ft_graph(ctx)
+        m = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+        n = L.nvxFindHomographyNode(ft["g"], L.vxGetReferenceFromDelay(ft["pts_delay"], -1), ft["kp_curr"], m,
+                                    ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, None)
+        assert L.vxGetStatus(n) == ovx.VX_SUCCESS
+        if mask_written_late:
+            src = L.vxCreateImage(ctx, 320, 240, ovx.VX_DF_IMAGE_U8)
+            msk = L.vxCreateImage(ctx, 320, 240, ovx.VX_DF_IMAGE_U8)
+            # created last, the copy is ordered after PyrLK and FindHomography (ties go by creation order); the detector waits for it
+            cp = L.nvxCopyImageNode(ft["g"], src, msk)
+            assert L.vxGetStatus(cp) == ovx.VX_SUCCESS
+            assert L.vxSetParameterByIndex(ft["nodes"]["det"], 2, msk) == ovx.VX_SUCCESS
+        assert L.vxVerifyGraph(ft["g"]) == ovx.VX_SUCCESS
+        return ft["g"]
+
+    f = ovx.graph_fusions(graph(False))
+    assert f["cells_in_pyrlk"] == 1 and f["merge_in_homography"] == 1
+    g = graph(True)
+    order = _order(g)
+    f = ovx.graph_fusions(g)
+    assert order.index(ovx.K_COPY_IMAGE) > order.index(ovx.K_PYRLK)
+    assert f["cells_in_pyrlk"] == 0 and f["merge_in_homography"] == 0
+    monkeypatch.setenv("VISUALSLAM_AMD_NO_FUSION", "1")
+    assert ovx.graph_fusions(graph(False))["merge_in_homography"] == 0
 
 
 # ---- user kernels, generic nodes, delays of matrices, uniform / ROI images (video stabilizer, SURVEY 8f-2) ----------
@@ -599,6 +633,9 @@ def test_stabilizer_graph_shape_orders_by_data(ctx):
     assert len(users) == 3 and pos[ovx.K_FIND_HOMOGRAPHY][0] < users[0] and users[2] < pos[ovx.K_WARP_PERSPECTIVE][0]
     assert pos[ovx.K_PYRLK][0] < pos[ovx.K_HARRIS_TRACK][0]
     assert ovx.query("vxQueryImage", gray, ovx.VX_IMAGE_WIDTH, C.c_uint32) == w
+    # the stabilizer's frame: ColorConvert inside the pyramid launch (virtual grey = level 0), cell pass inside PyrLK, and the
+    # detector's merge pass -- ordered after the three host nodes and the warp -- inside the FindHomography launch
+    assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 1, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 1, "merge_in_homography": 1}
 
 
 def test_delay_of_matrices(ctx):
@@ -793,18 +830,18 @@ def test_virtual_grey_image_becomes_level_0_of_the_pyramid_it_feeds(ctx, monkeyp
     for unsized in (False, True):           # the stabilizer's virtual image is created 0 x 0 (stabilizer.cpp:237)
         g, gray = _sfm_graph(ctx, unsized=unsized)
         assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS and _order(g) == order
-        assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 1, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 1}
+        assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 1, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 1, "merge_in_homography": 0}
         assert ovx.query("vxQueryImage", gray, ovx.VX_IMAGE_WIDTH, C.c_uint32) == 320
         # a second verification starts over and arrives at the same graph
         assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS and _order(g) == order
         assert ovx.graph_fusions(g)["virtual_gray_is_level0"] == 1
     g, _ = _sfm_graph(ctx, virtual=False)
     assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS and _order(g) == order
-    assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 0}
+    assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 1, "virtual_gray_is_level0": 0, "merge_in_homography": 0}
     g, _ = _sfm_graph(ctx, second_pyramid=True)
     assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS
     assert ovx.graph_fusions(g)["virtual_gray_is_level0"] == 0 and ovx.graph_fusions(g)["color_convert_in_pyramid"] == 0
     monkeypatch.setenv("VISUALSLAM_AMD_NO_FUSION", "1")
     g, _ = _sfm_graph(ctx)
     assert L.vxVerifyGraph(g) == ovx.VX_SUCCESS and _order(g) == order
-    assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 0, "virtual_gray_is_level0": 0}
+    assert ovx.graph_fusions(g) == {"color_convert_in_pyramid": 0, "cells_in_pyrlk": 0, "virtual_gray_is_level0": 0, "merge_in_homography": 0}

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 3, pass E: the detector's merge pass inside the FindHomography launch -- the new parity tests, the homography / stabilizer /
+# configs tests, then configs[4] fused and apart, then the whole GPU suite
+set -euo pipefail
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3e
+mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
+timeout -k 10 600 python -u -m pytest tests/test_gpu_ovx.py tests/test_gpu_homography.py tests/test_gpu_stabilizer.py tests/test_gpu_configs.py -m gpu -x -q --timeout 120 --timeout-method thread -k "homography or stabilizer or config4" > "$OUT/pytest_pair.log" 2>&1 || { tail -40 "$OUT/pytest_pair.log"; exit 1; }
+tail -3 "$OUT/pytest_pair.log"
+one() { timeout -k 10 150 python bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["repeat_frames_per_s"]; print(round(d["value"]), "(repeats: median", round(r["median"]), "min", round(r["min"]), "max", str(round(r["max"]))+")", "node ms", d.get("homography",{}).get("node_ms_in_timed_region"))'; }
+echo "c5 fused     : $(one --homography --steps 300)"
+echo "c5 fused     : $(one --homography --steps 300)"
+echo "c5 no fusion : $(VISUALSLAM_AMD_NO_FUSION=1 one --homography --steps 300)"
+echo "c2           : $(one --steps 300)"
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > "$OUT/pytest_gpu.log" 2>&1 || { tail -40 "$OUT/pytest_gpu.log"; exit 1; }
+tail -3 "$OUT/pytest_gpu.log"
+echo R3E_OK

@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "kernels.hpp"
+#include "merge_cells.hpp"
 
 namespace vsa {
 namespace {
@@ -52,10 +53,12 @@ struct HgArgs {
     uint8_t *mask;
     uint32_t *mask_count, *mask_count_host;
     uint32_t mask_cap;
-    uint32_t *keys;     // per hypothesis: inlier count + 1, or 0 when the hypothesis is invalid
-    float *hyp;         // per hypothesis: 9 floats, h22 = 1
-    uint32_t *ticket;   // workgroups that have published their hypothesis; 0 between launches
+    uint32_t *ticket;   // workgroups that have published their hypothesis; 0 between launches.  Behind it (homography_scratch_bytes):
+                        // keys, per hypothesis: inlier count + 1, or 0 when the hypothesis is invalid; hyp, per hypothesis: 9 floats, h22 = 1
 };
+// (derived where they are used rather than passed: two pointers are four scalar registers for the whole kernel)
+__device__ __forceinline__ uint32_t *hg_keys(const HgArgs &a) { return a.ticket + 4; }
+__device__ __forceinline__ float *hg_hyp(const HgArgs &a) { return reinterpret_cast<float *>(a.ticket + 4 + ((a.K + 3u) & ~3u)); }
 
 __device__ __forceinline__ uint32_t hg_n(const HgArgs &a)
 {
@@ -222,35 +225,56 @@ __device__ __forceinline__ bool hg_make_hypothesis(const HgArgs &a, uint32_t k, 
         }
         if (!ok) return false;
     }
-    // unit square -> quadrilateral for both point sets (Heckbert); the four quotients g, h share one division
-    double x[4], y[4], u[4], v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { x[j] = sp[j].x; y[j] = sp[j].y; u[j] = dp[j].x; v[j] = dp[j].y; }
-    const double adx1 = x[1] - x[2], adx2 = x[3] - x[2], ady1 = y[1] - y[2], ady2 = y[3] - y[2];
-    const double asx = ((x[0] - x[1]) + x[2]) - x[3], asy = ((y[0] - y[1]) + y[2]) - y[3];
-    const double aden = adx1 * ady2 - adx2 * ady1;
-    const double bdx1 = u[1] - u[2], bdx2 = u[3] - u[2], bdy1 = v[1] - v[2], bdy2 = v[3] - v[2];
-    const double bsx = ((u[0] - u[1]) + u[2]) - u[3], bsy = ((v[0] - v[1]) + v[2]) - v[3];
-    const double bden = bdx1 * bdy2 - bdx2 * bdy1;
+    // unit square -> quadrilateral for both point sets (Heckbert); the four quotients g, h share one division.  Written in stages
+    // (source side, destination side, quotients, adjugate of A, then H = B adj(A) row by row) with the coordinates converted where
+    // they are used, and the stages kept apart for the instruction scheduler: few binary64 values are live at any time, which is
+    // what lets the 96-register kernel build its hypothesis beside a thread's points.  Every value is the same expression as ever.
+    auto X = [&](int j) { return (double)sp[j].x; };
+    auto Y = [&](int j) { return (double)sp[j].y; };
+    auto U = [&](int j) { return (double)dp[j].x; };
+    auto V = [&](int j) { return (double)dp[j].y; };
+    double num[4], aden, bden;
+    {
+        const double adx1 = X(1) - X(2), adx2 = X(3) - X(2), ady1 = Y(1) - Y(2), ady2 = Y(3) - Y(2);
+        const double asx = ((X(0) - X(1)) + X(2)) - X(3), asy = ((Y(0) - Y(1)) + Y(2)) - Y(3);
+        aden = adx1 * ady2 - adx2 * ady1;
+        num[0] = asx * ady2 - adx2 * asy;
+        num[1] = adx1 * asy - asx * ady1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const double bdx1 = U(1) - U(2), bdx2 = U(3) - U(2), bdy1 = V(1) - V(2), bdy2 = V(3) - V(2);
+        const double bsx = ((U(0) - U(1)) + U(2)) - U(3), bsy = ((V(0) - V(1)) + V(2)) - V(3);
+        bden = bdx1 * bdy2 - bdx2 * bdy1;
+        num[2] = bsx * bdy2 - bdx2 * bsy;
+        num[3] = bdx1 * bsy - bsx * bdy1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (!(aden != 0.0) || !(bden != 0.0)) return false;
-    const double num[4] = { asx * ady2 - adx2 * asy, adx1 * asy - asx * ady1, bsx * bdy2 - bdx2 * bsy, bdx1 * bsy - bsx * bdy1 };
     const double quo = lane_select<4>(num, lane) / (lane < 2u ? aden : bden);
     const double ag = lane_bcast(quo, 0), ah = lane_bcast(quo, 1), bg = lane_bcast(quo, 2), bh = lane_bcast(quo, 3);
-    double A[9], B[9], adj[9], H[9];
-    A[0] = (x[1] - x[0]) + ag * x[1]; A[1] = (x[3] - x[0]) + ah * x[3]; A[2] = x[0];
-    A[3] = (y[1] - y[0]) + ag * y[1]; A[4] = (y[3] - y[0]) + ah * y[3]; A[5] = y[0];
-    A[6] = ag; A[7] = ah; A[8] = 1.0;
-    B[0] = (u[1] - u[0]) + bg * u[1]; B[1] = (u[3] - u[0]) + bh * u[3]; B[2] = u[0];
-    B[3] = (v[1] - v[0]) + bg * v[1]; B[4] = (v[3] - v[0]) + bh * v[3]; B[5] = v[0];
-    B[6] = bg; B[7] = bh; B[8] = 1.0;
-    adj[0] = A[4] * A[8] - A[5] * A[7]; adj[1] = A[2] * A[7] - A[1] * A[8]; adj[2] = A[1] * A[5] - A[2] * A[4];
-    adj[3] = A[5] * A[6] - A[3] * A[8]; adj[4] = A[0] * A[8] - A[2] * A[6]; adj[5] = A[2] * A[3] - A[0] * A[5];
-    adj[6] = A[3] * A[7] - A[4] * A[6]; adj[7] = A[1] * A[6] - A[0] * A[7]; adj[8] = A[0] * A[4] - A[1] * A[3];
+    __builtin_amdgcn_sched_barrier(0);
+    double adj[9], H[9];
+    {
+        double A[9];
+        A[0] = (X(1) - X(0)) + ag * X(1); A[1] = (X(3) - X(0)) + ah * X(3); A[2] = X(0);
+        A[3] = (Y(1) - Y(0)) + ag * Y(1); A[4] = (Y(3) - Y(0)) + ah * Y(3); A[5] = Y(0);
+        A[6] = ag; A[7] = ah; A[8] = 1.0;
+        adj[0] = A[4] * A[8] - A[5] * A[7]; adj[1] = A[2] * A[7] - A[1] * A[8]; adj[2] = A[1] * A[5] - A[2] * A[4];
+        adj[3] = A[5] * A[6] - A[3] * A[8]; adj[4] = A[0] * A[8] - A[2] * A[6]; adj[5] = A[2] * A[3] - A[0] * A[5];
+        adj[6] = A[3] * A[7] - A[4] * A[6]; adj[7] = A[1] * A[6] - A[0] * A[7]; adj[8] = A[0] * A[4] - A[1] * A[3];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < 3; ++r) {
+        double B[3];
+        if (r == 0) { B[0] = (U(1) - U(0)) + bg * U(1); B[1] = (U(3) - U(0)) + bh * U(3); B[2] = U(0); }
+        else if (r == 1) { B[0] = (V(1) - V(0)) + bg * V(1); B[1] = (V(3) - V(0)) + bh * V(3); B[2] = V(0); }
+        else { B[0] = bg; B[1] = bh; B[2] = 1.0; }
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            H[3 * r + c] = (B[3 * r] * adj[c] + B[3 * r + 1] * adj[3 + c]) + B[3 * r + 2] * adj[6 + c];
+        for (int c = 0; c < 3; ++c) H[3 * r + c] = (B[0] * adj[c] + B[1] * adj[3 + c]) + B[2] * adj[6 + c];
+        __builtin_amdgcn_sched_barrier(0);
+    }
     float e;
     if (!hg_to_f32_lanes(H, lane, e)) return false;
     elem = e;
@@ -391,12 +415,14 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
 
     // all hypotheses travel with the keys, so the winner's matrix is not one more dependent trip to memory
     const bool pre = a.K <= (uint32_t)HG_KPRE;
+    // (keys and hypotheses were published by workgroups on other XCDs: read past this XCD's L2, see find_homography_wg)
     if (pre)
-        for (uint32_t e = tid; e < 9u * a.K; e += HG_T) hyp_s[e] = a.hyp[e];
+        for (uint32_t e = tid; e < 9u * a.K; e += HG_T) hyp_s[e] = __hip_atomic_load(&hg_hyp(a)[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // best hypothesis: most inliers, ties to the lowest index
     unsigned long long best = 0;
     for (uint32_t k = tid; k < a.K; k += HG_T) {
-        const unsigned long long key = ((unsigned long long)a.keys[k] << 32) | (unsigned long long)(0xffffffffu - k);
+        const uint32_t kk = __hip_atomic_load(&hg_keys(a)[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long key = ((unsigned long long)kk << 32) | (unsigned long long)(0xffffffffu - k);
         best = key > best ? key : best;
     }
     uint32_t usable = 0;
@@ -422,7 +448,7 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
     if (usable >= 4 && key >= 5) {      // a valid hypothesis with at least 4 inliers
         cnt = key - 1u;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) H[i] = pre ? hyp_s[9 * kbest + i] : a.hyp[9 * kbest + i];
+        for (int i = 0; i < 9; ++i) H[i] = pre ? hyp_s[9 * kbest + i] : __hip_atomic_load(&hg_hyp(a)[9 * kbest + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         HG_STAMP(2);
 
         // normalisation over all usable correspondences (two passes, interleaved partials)
@@ -570,7 +596,12 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
         }
     }
     if (tid < 9) {   // transposed on the way out (homography_filter_node.cpp:87-91)
-        const float v = H[3 * (tid % 3) + tid / 3];
+        // (a chain of selects: indexed by the thread number the array would live in memory -- LDS, or scratch in the kernel
+        // that also has dynamic LDS -- for the whole refinement)
+        const uint32_t e = 3u * (tid % 3u) + tid / 3u;
+        float v = H[0];
+#pragma unroll
+        for (int i = 1; i < 9; ++i) v = e == (uint32_t)i ? H[i] : v;
         a.matrix[tid] = v;
         if (a.matrix_host) a.matrix_host[tid] = v;
     }
@@ -584,13 +615,13 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
 // One launch: workgroup k evaluates hypothesis k; the workgroup that publishes last (a ticket counter) goes on to
 // the refinement with its points still in registers.
 template <int NPT>
-__global__ __launch_bounds__(HG_T) void k_find_homography(HgArgs a, uint32_t bound)
+__device__ __forceinline__ void find_homography_wg(const HgArgs &a, uint32_t bound, const uint32_t k)
 {
     __shared__ float Hs[9];
     __shared__ int valid;
     __shared__ uint32_t red[4];
     __shared__ uint32_t is_last;
-    const uint32_t k = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     HG_STAMP(32);
     HgPoints<NPT> P;
     P.fetch(a, bound);
@@ -623,21 +654,420 @@ __global__ __launch_bounds__(HG_T) void k_find_homography(HgArgs a, uint32_t bou
     }
     HG_STAMP(36);
     cnt = block_sum_u32(cnt, red);
-    if (tid == 0) a.keys[k] = valid ? cnt + 1u : 0u;
-    if (tid < 9) a.hyp[9 * k + tid] = Hs[tid];
+    // Publish, then take a ticket.  The other workgroups may sit on other XCDs, behind other L2s.  A release / acquire pair at
+    // device scope would do, but on this GPU it is a write-back of the XCD's whole L2 in every workgroup and an invalidation of it
+    // in the last -- with the other camera streams' PyrLK waves living on their tiles in those L2s (57 such operations per
+    // frame).  Instead the ten words a workgroup publishes and the reads of them go past the L2s one by one (device-scope relaxed
+    // atomics: write-through stores, loads that do not hit a stale line), and the order is kept by hand: every thread waits for
+    // its own stores to be acknowledged (the workgroup-scope release of the barrier) before thread 0 takes the ticket.
+    if (tid == 0) __hip_atomic_store(&hg_keys(a)[k], valid ? cnt + 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 9) __hip_atomic_store(&hg_hyp(a)[9 * k + tid], Hs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     HG_STAMP(37);
-    // publish (release at device scope: the other workgroups may sit on other XCDs, behind other L2s), take a ticket
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);       // vmcnt = lgkmcnt = expcnt = 0: the stores above have been acknowledged
     __syncthreads();
     if (tid == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (t == a.K - 1u) ? 1u : 0u;
         if (t == a.K - 1u) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     __syncthreads();
     if (!is_last) return;
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);     // every thread of the last workgroup: see all published keys / hypotheses
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler: nothing below moves above the ticket
     HG_STAMP(0);
     hg_refine<NPT>(a, P, n);
+}
+
+template <int NPT>
+__global__ __launch_bounds__(HG_T) void k_find_homography(HgArgs a, uint32_t bound)
+{
+    find_homography_wg<NPT>(a, bound, blockIdx.x);
+}
+
+// ---- the same algorithm in at most 96 registers (arrays of at most HG_NPT * 256 correspondences) -----------------------
+// What the register-resident kernel above costs the OTHER camera streams is its footprint, not its work: a workgroup of four
+// 298-register waves needs a compute unit whose four SIMDs each hold at most two PyrLK waves, so it waits for the other
+// streams' PyrLK launches to drain, and the four hardware queues fall into step -- a do-nothing kernel with that footprint takes
+// the 32-stream bench from 38.3 k to 30.3 k frames/s, the real work another 1.7 k (profiles/r03_homography_dummy_kernels.txt).
+// Four PyrLK waves leave 96 registers per SIMD and 40 KB of LDS per compute unit; this form fits in them:
+//   * a thread's 16 correspondences: destination points in registers (32), source points in LDS (32 KB per workgroup, each thread
+//     reads back only what it wrote: no barrier);
+//   * the refit's 29 binary64 sums in three passes over the inliers (10 + 10 + 9 sums; every sum still sees its products in the
+//     same order), one barrier pair for all three; the current matrix waits in LDS meanwhile;
+//   * the 8 x 8 solve reads the sums from LDS where it needs them (row i on lane i), keeps the pivots and the back-substituted
+//     solution in scalar registers and takes L's columns from the rows by lane reads instead of holding a transposed copy.
+// Results are bit-identical to the kernel above and to the oracle.
+constexpr int HG_NPT = 16;
+static_assert(HG_NPT <= 16, "usable and inlier bits of a thread's points share one 32-bit register");
+
+// value of lane `src_lane` as a wave-uniform value the compiler keeps in scalar registers
+__device__ __forceinline__ double uniform64(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// wave-level part of block_tree_n for one value: lane 63 of each wave stores its wave's total
+__device__ __forceinline__ void wave_total_to_lds(double v, double (*w)[4], int q, uint32_t lane, uint32_t wv)
+{
+    v = wave_sum63(v);
+    if (lane == 63u) w[q][wv] = v;
+}
+
+// hg_solve_lanes with the 29 sums read from LDS (w[q][0..3]: the four wave totals of sum q) by the lane that needs them
+__device__ __forceinline__ bool hg_solve_lanes_lds(const double (*w)[4], uint32_t lane, double (&h)[8])
+{
+    const int i = (int)(lane & 7u);           // lanes 8..63 shadow rows 0..7 (their results are never used)
+    auto S = [&](int q) { return (w[q][0] + w[q][1]) + (w[q][2] + w[q][3]); };
+    double Lrow[8], D[8], Dself = 1.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) Lrow[c] = 0.0;
+    const double brow = S(21 + i);
+    bool pd = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = hg_midx(i, j <= i ? j : i);           // element (i, j) of the lower triangle; 0 above it and where hg_midx says so
+        const double m = S(q >= 0 ? q : 0);
+        double t = (j <= i && q >= 0) ? m : 0.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k) t -= (Lrow[k] * lane_bcast(Lrow[k], j)) * D[k];
+        const double d = lane_bcast(t, j);
+        pd = pd && (d > 1e-12);
+        D[j] = d;
+        const double l = t / d;
+        Lrow[j] = lane > (uint32_t)j ? l : 0.0;
+        if (lane == (uint32_t)j) Dself = d;
+    }
+    double z = brow;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double zk = lane_bcast(z, k);
+        if (lane > (uint32_t)k) z -= Lrow[k] * zk;
+    }
+    const double s0 = z / Dself;
+#pragma unroll
+    for (int r_ = 7; r_ >= 0; --r_) {
+        double r = s0;
+#pragma unroll
+        for (int k = r_ + 1; k < 8; ++k) r -= lane_bcast(Lrow[r_], k) * h[k];     // L[k][r_] lives in row k, on lane k
+        h[r_] = lane_bcast(r, r_);
+    }
+    return pd;
+}
+
+__device__ __forceinline__ void hg_fit_publish_lds(const double (*w)[4], const HgNorm &nm, uint32_t lane, float *Hnew, int *fit_ok)
+{
+    // a copy of the lane number the compiler cannot see through: the solve's per-lane indices and lane masks are loop invariants of
+    // the refit loop, and hoisted out of it they hold dozens of registers across the passes over the points
+    asm volatile("" : "+v"(lane));
+    double h[8];
+    bool ok = hg_solve_lanes_lds(w, lane, h);
+    const double Hn[9] = { h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 1.0 };
+    double G[9], Hd[9];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        G[3 * rr] = Hn[3 * rr] * nm.ss;
+        G[3 * rr + 1] = Hn[3 * rr + 1] * nm.ss;
+        G[3 * rr + 2] = (Hn[3 * rr + 2] - G[3 * rr] * nm.cx) - G[3 * rr + 1] * nm.cy;
+    }
+    const double g6[6] = { G[0], G[1], G[2], G[3], G[4], G[5] };
+    const double gq = lane_select<6>(g6, lane) / nm.sd;      // G[c] / sd, c = 0..5, in one division
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Hd[c] = lane_bcast(gq, c) + nm.cu * G[6 + c];
+        Hd[3 + c] = lane_bcast(gq, 3 + c) + nm.cv * G[6 + c];
+        Hd[6 + c] = G[6 + c];
+    }
+    float e;
+    ok = hg_to_f32_lanes(Hd, lane, e) && ok;
+    if (lane < 9) Hnew[lane] = ok ? e : (lane % 4u == 0u ? 1.0f : 0.0f);
+    if (lane == 0) *fit_ok = ok ? 1 : 0;
+}
+
+// The source points (32 KB) are the launch's DYNAMIC LDS: declared statically, the compiler sees that LDS allows four such
+// workgroups per compute unit, concludes that fewer than 97 registers buy no occupancy, and takes 97 whatever it is asked for --
+// one more than fits beside four PyrLK waves.
+constexpr size_t HG_LEAN_DYN_LDS = (size_t)HG_NPT * HG_T * sizeof(float2);
+struct HgLeanLds {                      // the static part
+    double wsum[HG_NACC][4];
+    unsigned long long best_w[4];
+    float hyp_s[HG_KPRE * 9];
+    float Hs[9], Hnew[9], Hcur[9];
+    uint32_t red[4];
+    int valid, fit_ok;
+    uint32_t is_last;
+};
+
+// one pass of the refit over this thread's inliers: a third of the 29 sums, each one the same chain of fused multiply-adds over
+// the points in the same order as in the one-pass form (two passes of 15 + 14 sums do not fit in the registers)
+//   pass 0: sums 0..5 (x, y only), 21, 22, 24, 25 (x u, y u, x v, y v);  pass 1: 6..11, 23, 26 (u, v), 27, 28;  pass 2: 12..17, 18..20
+template <int PASS, typename LDS>
+__device__ __forceinline__ void hg_refit_pass(const LDS &L, const float2 (&pd)[HG_NPT], uint32_t inl, const HgNorm &nm,
+                                              uint32_t tid, uint32_t lane, uint32_t wv, double (*w)[4])
+{
+    constexpr int N = PASS == 0 ? 10 : (PASS == 1 ? 10 : 9);
+    constexpr int SUM[3][10] = { { 0, 1, 2, 3, 4, 5, 21, 22, 24, 25 }, { 6, 7, 8, 9, 10, 11, 23, 26, 27, 28 },
+                                 { 12, 13, 14, 15, 16, 17, 18, 19, 20, -1 } };
+    double acc[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < HG_NPT; ++j) {
+        if (!((inl >> j) & 1u)) continue;
+        const float2 s = L.src[tid + (uint32_t)j * HG_T];
+        // opaque copies: keeps the compiler from hoisting the points' binary64 terms out of the pass (and across passes)
+        float sx = s.x, sy = s.y, dx = pd[j].x, dy = pd[j].y;
+        asm volatile("" : "+v"(sx), "+v"(sy), "+v"(dx), "+v"(dy));
+        const double x = ((double)sx - nm.cx) * nm.ss, y = ((double)sy - nm.cy) * nm.ss;
+        const double u = ((double)dx - nm.cu) * nm.sd, v = ((double)dy - nm.cv) * nm.sd;
+#define ACC(k, p, q) acc[k] = fma(p, q, acc[k])
+        if (PASS == 0) {
+            ACC(0, x, x); ACC(1, x, y); ACC(2, x, 1.0); ACC(3, y, y); ACC(4, y, 1.0); ACC(5, 1.0, 1.0);
+            ACC(6, x, u); ACC(7, y, u); ACC(8, x, v); ACC(9, y, v);
+        } else if (PASS == 1) {
+            const double q0 = -(x * u), q1 = -(y * u), r0 = -(x * v), r1 = -(y * v);
+            ACC(0, x, q0); ACC(1, x, q1); ACC(2, y, q0); ACC(3, y, q1); ACC(4, 1.0, q0); ACC(5, 1.0, q1);
+            ACC(6, 1.0, u); ACC(7, 1.0, v);
+            ACC(8, q0, u); ACC(8, r0, v); ACC(9, q1, u); ACC(9, r1, v);
+        } else {
+            const double q0 = -(x * u), q1 = -(y * u), r0 = -(x * v), r1 = -(y * v);
+            ACC(0, x, r0); ACC(1, x, r1); ACC(2, y, r0); ACC(3, y, r1); ACC(4, 1.0, r0); ACC(5, 1.0, r1);
+            ACC(6, q0, q0); ACC(6, r0, r0); ACC(7, q0, q1); ACC(7, r0, r1); ACC(8, q1, q1); ACC(8, r1, r1);
+        }
+#undef ACC
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) wave_total_to_lds(acc[q], w, SUM[PASS][q], lane, wv);
+    __builtin_amdgcn_sched_barrier(0);      // the passes one after the other: interleaved they would all hold their sums at once
+}
+
+template <typename LDS>
+__device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const float2 (&pd)[HG_NPT], uint32_t us, uint32_t n)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    // the mask's item count is known already (written here, the two pointers are not carried through the refinement)
+    if (tid == 0 && a.mask_count) {
+        *a.mask_count = n;
+        if (a.mask_count_host) *a.mask_count_host = n;
+    }
+    // (keys and hypotheses were published by workgroups on other XCDs: read past this XCD's L2, see find_homography_wg)
+    const bool pre = a.K <= (uint32_t)HG_KPRE;
+    if (pre)
+        for (uint32_t e = tid; e < 9u * a.K; e += HG_T) L.hyp_s[e] = __hip_atomic_load(&hg_hyp(a)[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long best = 0;
+    for (uint32_t k = tid; k < a.K; k += HG_T) {
+        const uint32_t kk = __hip_atomic_load(&hg_keys(a)[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long key = ((unsigned long long)kk << 32) | (unsigned long long)(0xffffffffu - k);
+        best = key > best ? key : best;
+    }
+    uint32_t usable = __popc(us);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+        usable += __shfl_xor(usable, off);
+    }
+    if (lane == 0) { L.best_w[wv] = best; L.red[wv] = usable; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) best = L.best_w[w] > best ? L.best_w[w] : best;
+    usable = L.red[0] + L.red[1] + L.red[2] + L.red[3];
+    const uint32_t key = (uint32_t)(best >> 32), kbest = 0xffffffffu - (uint32_t)(best & 0xffffffffu);
+
+    // the current matrix lives in LDS (L.Hcur, written by threads 0..8) and is in registers only where it is used; the barriers
+    // of the sums below stand between its writes and its reads
+    if (tid < 9) L.Hcur[tid] = (tid % 4u == 0u) ? 1.0f : 0.0f;
+    // from here on `us` carries the inlier bits of the current matrix in its upper half (one register for both sets)
+    uint32_t cnt = 0;
+    if (usable >= 4 && key >= 5) {      // a valid hypothesis with at least 4 inliers
+        cnt = key - 1u;
+        if (tid < 9) L.Hcur[tid] = pre ? L.hyp_s[9 * kbest + tid] : __hip_atomic_load(&hg_hyp(a)[9 * kbest + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // normalisation over all usable correspondences (two passes, interleaved partials)
+        double c4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int j = 0; j < HG_NPT; ++j)
+            if ((us >> j) & 1u) {
+                const float2 s = L.src[tid + (uint32_t)j * HG_T];
+                c4[0] += (double)s.x; c4[1] += (double)s.y; c4[2] += (double)pd[j].x; c4[3] += (double)pd[j].y;
+            }
+        block_tree_n<4>(c4, L.wsum);
+        block_tree_read<4>(c4, L.wsum);
+        const double cntd = (double)usable;
+        HgNorm nm;
+        nm.cx = uniform64(c4[0] / cntd); nm.cy = uniform64(c4[1] / cntd); nm.cu = uniform64(c4[2] / cntd); nm.cv = uniform64(c4[3] / cntd);
+        double d2[2] = { 0, 0 };
+#pragma unroll
+        for (int j = 0; j < HG_NPT; ++j)
+            if ((us >> j) & 1u) {
+                const float2 s = L.src[tid + (uint32_t)j * HG_T];
+                d2[0] += fabs((double)s.x - nm.cx) + fabs((double)s.y - nm.cy);
+                d2[1] += fabs((double)pd[j].x - nm.cu) + fabs((double)pd[j].y - nm.cv);
+            }
+        block_tree_n<2>(d2, L.wsum);
+        block_tree_read<2>(d2, L.wsum);
+        const bool norm_ok = d2[0] > 0.0 && d2[1] > 0.0;
+        nm.ss = uniform64(norm_ok ? cntd / d2[0] : 0.0);
+        nm.sd = uniform64(norm_ok ? cntd / d2[1] : 0.0);
+        {
+            float H[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) H[i] = L.Hcur[i];
+#pragma unroll
+            for (int j = 0; j < HG_NPT; ++j)
+                us |= (((us >> j) & 1u) & (uint32_t)hg_inlier(H, L.src[tid + (uint32_t)j * HG_T], pd[j], a.thr2)) << (16 + j);
+        }
+
+        for (uint32_t r = 0; r < a.max_refine && norm_ok; ++r) {
+            __syncthreads();      // the previous round's readers are done with the sums
+            hg_refit_pass<0>(L, pd, us >> 16, nm, tid, lane, wv, L.wsum);
+            hg_refit_pass<1>(L, pd, us >> 16, nm, tid, lane, wv, L.wsum);
+            hg_refit_pass<2>(L, pd, us >> 16, nm, tid, lane, wv, L.wsum);
+            __syncthreads();
+            if (wv == 0) hg_fit_publish_lds(L.wsum, nm, lane, L.Hnew, &L.fit_ok);
+            __syncthreads();
+            if (!L.fit_ok) break;     // block-uniform
+            float Hn[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Hn[i] = L.Hnew[i];
+            uint32_t is = 0;
+#pragma unroll
+            for (int j = 0; j < HG_NPT; ++j)
+                is |= (((us >> j) & 1u) & (uint32_t)hg_inlier(Hn, L.src[tid + (uint32_t)j * HG_T], pd[j], a.thr2)) << j;
+            uint32_t c = __popc(is), diff = __popc(is ^ (us >> 16));
+            c = block_sum_u32(c, L.red);
+            diff = block_sum_u32(diff, L.red);
+            if (c < cnt) break;
+            if (tid < 9) L.Hcur[tid] = L.Hnew[tid];     // (Hnew is next written after the next round's barriers)
+            cnt = c;
+            us = (us & 0xffffu) | (is << 16);
+            if (diff == 0) break;
+        }
+    }
+    // (an opaque copy of the thread number for the write-out: the sixteen "i < n" lane masks, "tid < 9" and "tid == 0" would otherwise
+    // be kept in scalar registers from the kernel's head to here)
+    uint32_t t2 = tid;
+    asm volatile("" : "+v"(t2));
+    uint8_t *mask = a.mask;
+    asm volatile("" : "+s"(mask));      // (likewise: "is there a mask" is first asked where the point count is read)
+    if (mask) {
+#pragma unroll
+        for (int j = 0; j < HG_NPT; ++j) {
+            const uint32_t i = t2 + (uint32_t)j * HG_T;
+            if (i < n) mask[i] = (cnt != 0 && ((us >> (16 + j)) & 1u)) ? 255 : 0;
+        }
+    }
+    __syncthreads();      // L.Hcur's last update
+    if (t2 < 9) {   // transposed on the way out (homography_filter_node.cpp:87-91)
+        const float v = L.Hcur[3u * (t2 % 3u) + t2 / 3u];
+        a.matrix[t2] = v;
+        if (a.matrix_host) a.matrix_host[t2] = v;
+    }
+}
+
+__device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_t bound, const uint32_t k)
+{
+    __shared__ HgLeanLds Ls;
+    extern __shared__ __attribute__((aligned(16))) float2 hg_src_points[];
+    struct View {       // what the functions above see: the static part by reference, the points through the dynamic array
+        float2 *src; double (&wsum)[HG_NACC][4]; unsigned long long (&best_w)[4]; float (&hyp_s)[HG_KPRE * 9];
+        float (&Hs)[9], (&Hnew)[9], (&Hcur)[9]; uint32_t (&red)[4]; int &valid, &fit_ok; uint32_t &is_last;
+    };
+    View L{ hg_src_points, Ls.wsum, Ls.best_w, Ls.hyp_s, Ls.Hs, Ls.Hnew, Ls.Hcur, Ls.red, Ls.valid, Ls.fit_ok, Ls.is_last };
+    const uint32_t tid = threadIdx.x;
+    // The loads do not wait for the item counts: the host guarantees bound <= HG_NPT * HG_T <= the arrays' capacities.  Source points go
+    // from memory straight into LDS (global_load_lds, 16 bytes = two points per lane, no registers in between); what lies at and
+    // beyond `bound` is never read back (the usable test below starts with i < n <= bound).
+    {
+        const uint32_t wave_first = tid & ~63u;
+#pragma unroll
+        for (int m = 0; m < HG_NPT / 2; ++m) {
+            const uint32_t f = (uint32_t)m * HG_T + tid;                 // this lane's pair of points: 2 f, 2 f + 1
+            if (2u * f + 1u < bound)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(reinterpret_cast<const float4 *>(a.src) + f),
+                                                 (__attribute__((address_space(3))) void *)(L.src + 2u * ((uint32_t)m * HG_T + wave_first)), 16, 0, 0);
+            else if (2u * f < bound) L.src[2u * f] = a.src[2u * f];
+        }
+    }
+    float2 pd[HG_NPT];
+#pragma unroll
+    for (int j = 0; j < HG_NPT; ++j) {
+        const uint32_t i = tid + (uint32_t)j * HG_T;
+        pd[j] = make_float2(-1.0f, -1.0f);
+        if (i < bound) pd[j] = a.dst[i];
+    }
+    const uint32_t n = hg_n(a);
+    if (tid < 64) {
+        float e;
+        const bool ok = hg_make_hypothesis(a, k, n, tid, e);
+        if (tid < 9) L.Hs[tid] = ok ? e : (tid % 4u == 0u ? 1.0f : 0.0f);
+        if (tid == 0) L.valid = ok ? 1 : 0;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's part of the source points is in LDS (the other waves': the barrier)
+    __syncthreads();
+    float H[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] = L.Hs[i];
+    const bool valid = L.valid != 0;
+    uint32_t us = 0, cnt = 0;
+    uint32_t t1 = tid;
+    asm volatile("" : "+v"(t1));      // (the points' indices are re-derived here, not held in sixteen registers since the loads above)
+#pragma unroll
+    for (int j = 0; j < HG_NPT; ++j) {
+        const float2 s = L.src[t1 + (uint32_t)j * HG_T];
+        const uint32_t u = (t1 + (uint32_t)j * HG_T < n && hg_usable(s, pd[j])) ? 1u : 0u;
+        us |= u << j;
+        cnt += u & (uint32_t)hg_inlier(H, s, pd[j], a.thr2);
+    }
+    cnt = block_sum_u32(valid ? cnt : 0u, L.red);
+    // publish past the L2s, then take a ticket (see find_homography_wg)
+    if (tid == 0) __hip_atomic_store(&hg_keys(a)[k], valid ? cnt + 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 9) __hip_atomic_store(&hg_hyp(a)[9 * k + tid], L.Hs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.is_last = (t == a.K - 1u) ? 1u : 0u;
+        if (t == a.K - 1u) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!L.is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    hg_refine_lean(a, L, pd, us, n);
+}
+
+// 48: the attribute counts the unified register file in halves (pyrlk.hip)
+__global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_find_homography_lean(HgArgs a, uint32_t bound)
+{
+    find_homography_lean_wg(a, bound, blockIdx.x);
+}
+// ... and with a detector node's merge pass as workgroup 0 (k_find_homography_merge below is the any-size form)
+__global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_find_homography_lean_merge(HgArgs a, uint32_t bound, MergeArgs m)
+{
+    if (blockIdx.x == 0) {
+        VSA_SHORT_KERNEL_PRIORITY();
+        merge_compact_wg<(uint32_t)HG_T, 8u, 13u>(m);
+        return;
+    }
+    find_homography_lean_wg(a, bound, blockIdx.x - 1u);
+}
+
+// FindHomography and a detector node's merge pass in one launch (launch_find_homography_with_merge): both only read what PyrLK
+// (and, for the merge, the cell pass) left, neither reads what the other writes.  Workgroup 0 runs the merge on its four waves
+// (merge_cells.hpp) and is long done when the refinement ends; workgroups 1 .. K are the hypotheses.  What a camera stream saves is
+// the merge's launch: its wait for a compute unit with room, its run and the gap in front of it, while the stream's hardware
+// queue is held by the homography's latency chain anyway.
+constexpr uint32_t HG_MERGE_KT = 8, HG_MERGE_KC = 13;   // rounds per block of the merge's walks: this kernel's register budget is the refit's
+template <int NPT>
+__global__ __launch_bounds__(HG_T) void k_find_homography_merge(HgArgs a, uint32_t bound, MergeArgs m)
+{
+    if (blockIdx.x == 0) {
+        VSA_SHORT_KERNEL_PRIORITY();
+        merge_compact_wg<(uint32_t)HG_T, HG_MERGE_KT, HG_MERGE_KC>(m);
+        return;
+    }
+    find_homography_wg<NPT>(a, bound, blockIdx.x - 1u);
 }
 
 }  // namespace
@@ -664,10 +1094,12 @@ size_t homography_scratch_bytes(uint32_t hypotheses)
     return (size_t)hypotheses * (sizeof(uint32_t) + 9 * sizeof(float)) + 32;     // ticket word (16 B), keys padded to 16 B, hypotheses
 }
 
-hipError_t launch_find_homography(const HomographyParams &p, hipStream_t stream)
+namespace {
+// kernel arguments for p; `bound`: what the arrays' capacities allow the point count to be (it lives in device memory)
+bool hg_setup(const HomographyParams &p, HgArgs &a, uint32_t &bound)
 {
-    if (p.hypotheses == 0) return hipErrorInvalidValue;
-    HgArgs a{};
+    if (p.hypotheses == 0) return false;
+    a = HgArgs{};
     a.src = static_cast<const float2 *>(p.src); a.dst = static_cast<const float2 *>(p.dst);
     a.src_count = p.src_count; a.dst_count = p.dst_count; a.src_cap = p.src_capacity; a.dst_cap = p.dst_capacity;
     a.thr2 = p.threshold * p.threshold;
@@ -675,14 +1107,51 @@ hipError_t launch_find_homography(const HomographyParams &p, hipStream_t stream)
     a.matrix = p.matrix; a.matrix_host = p.matrix_host;
     a.mask = p.mask; a.mask_count = p.mask_count; a.mask_count_host = p.mask_count_host; a.mask_cap = p.mask_capacity;
     a.ticket = static_cast<uint32_t *>(p.scratch);          // at a fixed place, whatever the hypothesis count
-    a.keys = a.ticket + 4;
-    a.hyp = reinterpret_cast<float *>(a.keys + ((p.hypotheses + 3u) & ~3u));
-    // the point count lives in device memory; the capacities bound it
-    uint32_t bound = p.src_capacity < p.dst_capacity ? p.src_capacity : p.dst_capacity;
+    bound = p.src_capacity < p.dst_capacity ? p.src_capacity : p.dst_capacity;
     if (p.mask && p.mask_capacity < bound) bound = p.mask_capacity;
+    return true;
+}
+bool hg_generic(uint32_t bound)
+{
     const bool force_generic = getenv("VISUALSLAM_AMD_HG_GENERIC") != nullptr;   // tests: exercise the any-size kernel
-    if (bound <= 16u * HG_T && !force_generic) hipLaunchKernelGGL(k_find_homography<16>, dim3(p.hypotheses), dim3(HG_T), 0, stream, a, bound);
+    return bound > 16u * HG_T || force_generic;
+}
+constexpr size_t HG_MERGE_MAX_LDS = 32u * 1024u;   // the merge's cell flags, beside the refinement's static arrays
+}  // namespace
+
+hipError_t launch_find_homography(const HomographyParams &p, hipStream_t stream)
+{
+    HgArgs a{};
+    uint32_t bound = 0;
+    if (!hg_setup(p, a, bound)) return hipErrorInvalidValue;
+    if (!hg_generic(bound)) {
+        if (getenv("VSA_EXP_HG_FAT")) hipLaunchKernelGGL(k_find_homography<16>, dim3(p.hypotheses), dim3(HG_T), 0, stream, a, bound);
+        else hipLaunchKernelGGL(k_find_homography_lean, dim3(p.hypotheses), dim3(HG_T), HG_LEAN_DYN_LDS, stream, a, bound);
+    }
     else hipLaunchKernelGGL(k_find_homography<0>, dim3(p.hypotheses), dim3(HG_T), 0, stream, a, bound);
+    return hipGetLastError();
+}
+
+bool find_homography_merge_fusable(const HomographyParams &p, const CornerTrackParams &ct)
+{
+    HgArgs a{};
+    MergeArgs m{};
+    uint32_t bound = 0;
+    size_t lds = 0;
+    return hg_setup(p, a, bound) && merge_setup(ct, m, lds) && lds <= HG_MERGE_MAX_LDS;
+}
+
+hipError_t launch_find_homography_with_merge(const HomographyParams &p, const CornerTrackParams &ct, hipStream_t stream)
+{
+    HgArgs a{};
+    MergeArgs m{};
+    uint32_t bound = 0;
+    size_t lds = 0;
+    if (!hg_setup(p, a, bound) || !merge_setup(ct, m, lds) || lds > HG_MERGE_MAX_LDS) return hipErrorInvalidValue;
+    const dim3 grid(p.hypotheses + 1u);
+    if (!hg_generic(bound))
+        hipLaunchKernelGGL(k_find_homography_lean_merge, grid, dim3(HG_T), lds > HG_LEAN_DYN_LDS ? lds : HG_LEAN_DYN_LDS, stream, a, bound, m);
+    else hipLaunchKernelGGL(k_find_homography_merge<0>, grid, dim3(HG_T), lds, stream, a, bound, m);
     return hipGetLastError();
 }
 

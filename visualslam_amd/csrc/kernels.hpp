@@ -154,5 +154,9 @@ struct HomographyParams {
 uint32_t homography_hypotheses(float confidence, float outlier_ratio, uint32_t max_estimate_iters);
 size_t homography_scratch_bytes(uint32_t hypotheses);
 hipError_t launch_find_homography(const HomographyParams &p, hipStream_t stream);
+// FindHomography and the MERGE pass of a detector node (whose cell pass has already run, e.g. inside the PyrLK launch) in one launch:
+// both read PyrLK's output, neither reads what the other writes.  Results are those of launch_find_homography + launch_corner_merge.
+bool find_homography_merge_fusable(const HomographyParams &p, const CornerTrackParams &ct);
+hipError_t launch_find_homography_with_merge(const HomographyParams &p, const CornerTrackParams &ct, hipStream_t stream);
 
 }  // namespace vsa

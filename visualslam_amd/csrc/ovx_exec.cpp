@@ -205,9 +205,9 @@ vx_status do_corner_track(Detector det, _vx_image *in, _vx_array *out, _vx_image
     return hip_status(merge_only ? launch_corner_merge(p, stream) : launch_corner_track(p, stream));
 }
 
-vx_status do_find_homography(_vx_array *src, _vx_array *dst, _vx_matrix *mat, vx_enum method, float threshold,
-                             uint32_t max_estimate, uint32_t max_refine, float confidence, float outlier_ratio,
-                             _vx_array *mask, void *scratch, size_t scratch_size, hipStream_t stream)
+vx_status prep_find_homography(_vx_array *src, _vx_array *dst, _vx_matrix *mat, vx_enum method, float threshold,
+                               uint32_t max_estimate, uint32_t max_refine, float confidence, float outlier_ratio,
+                               _vx_array *mask, void *scratch, size_t scratch_size, HomographyParams *out)
 {
     if (!src || !dst || !mat) return VX_ERROR_INVALID_PARAMETERS;
     if (method != NVX_FIND_HOMOGRAPHY_METHOD_RANSAC) return VX_ERROR_NOT_SUPPORTED;
@@ -215,7 +215,8 @@ vx_status do_find_homography(_vx_array *src, _vx_array *dst, _vx_matrix *mat, vx
     if (mat->data_type != VX_TYPE_FLOAT32 || mat->cols != 3 || mat->rows != 3) return VX_ERROR_INVALID_DIMENSION;
     if (mask && mask->item_type != VX_TYPE_UINT8) return VX_ERROR_INVALID_TYPE;
     if (!(threshold > 0.0f)) return VX_ERROR_INVALID_VALUE;
-    HomographyParams p{};
+    HomographyParams &p = *out;
+    p = HomographyParams{};
     p.hypotheses = homography_hypotheses(confidence, outlier_ratio, max_estimate);
     if (scratch_size < homography_scratch_bytes(p.hypotheses)) return VX_ERROR_NO_MEMORY;
     vx_status s = ensure_array(src);
@@ -235,7 +236,17 @@ vx_status do_find_homography(_vx_array *src, _vx_array *dst, _vx_matrix *mat, vx
     p.mask_count_host = mask ? mask->count_mirror : nullptr;
     p.mask_capacity = mask ? (uint32_t)mask->capacity : 0;
     p.scratch = scratch;
-    return hip_status(launch_find_homography(p, stream));
+    return VX_SUCCESS;
+}
+
+vx_status do_find_homography(_vx_array *src, _vx_array *dst, _vx_matrix *mat, vx_enum method, float threshold,
+                             uint32_t max_estimate, uint32_t max_refine, float confidence, float outlier_ratio,
+                             _vx_array *mask, void *scratch, size_t scratch_size, hipStream_t stream)
+{
+    HomographyParams p{};
+    const vx_status s = prep_find_homography(src, dst, mat, method, threshold, max_estimate, max_refine, confidence, outlier_ratio,
+                                             mask, scratch, scratch_size, &p);
+    return s != VX_SUCCESS ? s : hip_status(launch_find_homography(p, stream));
 }
 
 // the matrix as stored is M column by column: data[3c + r] = M[r][c] (truncate_transform_node.cpp:163-165)
@@ -304,8 +315,45 @@ vx_status homography_node_scratch(_vx_node *n, hipStream_t stream)
     return VX_SUCCESS;
 }
 
+// The two nodes' parameters as they are NOW (applications rebind them between runs); false: anything keeps the pair from sharing a launch
+static bool prep_pair(_vx_node *fh, _vx_node *ht, hipStream_t stream, HomographyParams *hp, CornerTrackParams *ct)
+{
+    if (!ht->cells_done) return false;      // this run's cell pass did not ride in the PyrLK launch
+    if (homography_node_scratch(fh, stream) != VX_SUCCESS || node_scratch(ht) != VX_SUCCESS) return false;
+    auto *m = param<_vx_scalar>(fh, 3, VX_TYPE_SCALAR);
+    if (prep_find_homography(param<_vx_array>(fh, 0, VX_TYPE_ARRAY), param<_vx_array>(fh, 1, VX_TYPE_ARRAY),
+                             param<_vx_matrix>(fh, 2, VX_TYPE_MATRIX), m ? m->v.e : 0, scalar_f32(fh, 4), scalar_u32(fh, 5),
+                             scalar_u32(fh, 6), scalar_f32(fh, 7), scalar_f32(fh, 8), param<_vx_array>(fh, 9, VX_TYPE_ARRAY),
+                             fh->scratch, fh->scratch_size, hp) != VX_SUCCESS) return false;
+    const bool harris = ht->kind == K_HARRIS_TRACK;
+    if (prep_corner_track(harris ? kHarris : kFast, param<_vx_image>(ht, 0, VX_TYPE_IMAGE), param<_vx_array>(ht, 1, VX_TYPE_ARRAY),
+                          param<_vx_image>(ht, 2, VX_TYPE_IMAGE), param<_vx_array>(ht, 3, VX_TYPE_ARRAY),
+                          harris ? scalar_f32(ht, 4) : 0.0f, harris ? scalar_f32(ht, 5) : (float)scalar_u32(ht, 5),
+                          harris ? 0u : scalar_u32(ht, 4), scalar_u32(ht, 6), param<_vx_scalar>(ht, 7, VX_TYPE_SCALAR) ? ht->dev_num_corners : nullptr,
+                          ht->num_corners_mirror, ht->scratch, ht->scratch_size, ct) != VX_SUCCESS) return false;
+    return find_homography_merge_fusable(*hp, *ct);
+}
+
 vx_status run_node(_vx_node *n, hipStream_t stream)
 {
+    if (n->pair) {
+        if (!n->pair_leader && n->pair_done) {      // the leader's launch did this node's work
+            n->pair_done = false;
+            return VX_SUCCESS;
+        }
+        if (n->pair_leader) {
+            _vx_node *fh = n->kind == K_FIND_HOMOGRAPHY ? n : n->pair, *ht = fh == n ? n->pair : n;
+            HomographyParams hp{};
+            CornerTrackParams ct{};
+            ht->pair_done = fh->pair_done = false;
+            if (prep_pair(fh, ht, stream, &hp, &ct)) {
+                const vx_status s = hip_status(launch_find_homography_with_merge(hp, ct, stream));
+                ht->cells_done = false;
+                n->pair->pair_done = s == VX_SUCCESS;
+                return s;
+            }
+        }
+    }
     switch (n->kind) {
     case K_FIND_HOMOGRAPHY: {
         vx_status s = homography_node_scratch(n, stream);

@@ -166,6 +166,11 @@ struct _vx_node : _vx_reference {
     _vx_node *fused_cvt = nullptr;    // K_GAUSSIAN_PYRAMID: the ColorConvert node whose RGBX input this node converts itself
     _vx_node *fused_cells = nullptr;  // K_PYRLK: the HarrisTrack node whose cell pass may run inside this node's launch (vxVerifyGraph)
     bool cells_done = false;          // K_HARRIS_TRACK: this execution's cell pass has run in the PyrLK node's launch; merge only
+    // A FindHomography node and a detector node whose merge pass may share ONE launch (vxVerifyGraph): each is the other's `pair`;
+    // the one that comes first in the order leads (launches for both), the other then finds pair_done set and does nothing.
+    _vx_node *pair = nullptr;
+    bool pair_leader = false;
+    bool pair_done = false;
     bool perf_enabled = false;        // vxDirective on this node alone (extension: narrower than the context-wide switch)
     void *scratch = nullptr;
     size_t scratch_size = 0;

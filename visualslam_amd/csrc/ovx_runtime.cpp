@@ -1400,15 +1400,19 @@ extern "C" int visualslam_amd_graph_order(vx_graph graph, int *kinds, int max_ki
 
 /* not part of the reference API: what vxVerifyGraph decided to fuse (for tests): out[0] = ColorConvert nodes converted inside the
  * pyramid's first launch, out[1] = detector nodes whose cell pass rides in the PyrLK launch, out[2] = virtual grey images made
- * views of a pyramid's level 0 */
+ * views of a pyramid's level 0, out[3] (when max_out >= 4) = FindHomography nodes sharing a launch with a detector node's merge pass */
 extern "C" int visualslam_amd_graph_fusions(vx_graph graph, int *out, int max_out)
 {
     if (!valid(graph, VX_TYPE_GRAPH) || !graph->verified || !out || max_out < 3) return -1;
     out[0] = out[1] = 0;
+    int pairs = 0;
     for (_vx_node *nd : graph->nodes) {
         if (nd->fused_away) ++out[0];
         if (nd->fused_cells) ++out[1];
+        if (nd->pair && nd->kind == K_FIND_HOMOGRAPHY) ++pairs;
     }
     out[2] = (int)graph->aliased.size();
-    return 3;
+    if (max_out < 4) return 3;
+    out[3] = pairs;
+    return 4;
 }

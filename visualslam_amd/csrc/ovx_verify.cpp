@@ -227,7 +227,8 @@ vx_status verify_graph(_vx_graph *g)
     // (feature_tracker.cpp:360-362,386,393) -- run as ONE launch that reads the colour frame.  Legal when nothing reads
     // the grey image between the two nodes; the ColorConvert node then does nothing when executed.
     {
-        for (_vx_node *nd : g->nodes) { nd->fused_away = false; nd->fused_cvt = nullptr; nd->fused_cells = nullptr; nd->cells_done = false; }
+        for (_vx_node *nd : g->nodes) { nd->fused_away = false; nd->fused_cvt = nullptr; nd->fused_cells = nullptr; nd->cells_done = false;
+                                         nd->pair = nullptr; nd->pair_leader = false; nd->pair_done = false; }
         std::vector<size_t> pos(n, 0);
         for (size_t k = 0; k < n; ++k)
             for (size_t i = 0; i < n; ++i)
@@ -277,6 +278,31 @@ vx_status verify_graph(_vx_graph *g)
                 for (size_t b = 0; b < n && ok; ++b)
                     if (pos[b] >= pos[li] && pos[b] < pos[hi] && intersects(wr[b], inputs)) ok = false;
                 if (ok) lk->fused_cells = ht;
+                break;
+            }
+        }
+        // A FindHomography node on the matches (stabilizer.cpp:264-273, SfM.cpp:1576-1578) and a detector node whose cell pass rides
+        // in a PyrLK launch: what is left of the detector node, its merge pass, and the homography both read what PyrLK wrote and
+        // neither reads what the other writes, so they run as ONE launch (homography.hip) at the place of whichever comes first.
+        // Legal when the later node can move up: it does not depend on the earlier one, and no node between the two writes what
+        // it reads, or reads or writes what it writes.
+        for (size_t fi = 0; fi < n && getenv("VISUALSLAM_AMD_NO_FUSION") == nullptr && getenv("VSA_EXP_NO_PAIR") == nullptr; ++fi) {
+            _vx_node *fh = g->nodes[fi];
+            if (fh->kind != K_FIND_HOMOGRAPHY || fh->pair) continue;
+            for (size_t hi = 0; hi < n; ++hi) {
+                _vx_node *ht = g->nodes[hi];
+                if ((ht->kind != K_HARRIS_TRACK && ht->kind != K_FAST_TRACK) || ht->pair) continue;
+                size_t li = n;
+                for (size_t q = 0; q < n; ++q) if (g->nodes[q]->kind == K_PYRLK && g->nodes[q]->fused_cells == ht) li = q;
+                const size_t a = pos[fi] < pos[hi] ? fi : hi, b = a == fi ? hi : fi;      // a leads, b moves up to a's place
+                if (li == n || pos[li] > pos[a]) continue;
+                bool ok = !intersects(wr[a], rd[b]) && !intersects(wr[b], rd[a]) && !intersects(wr[a], wr[b]);
+                for (size_t c = 0; c < n && ok; ++c)
+                    if (pos[c] > pos[a] && pos[c] < pos[b] &&
+                        (intersects(wr[c], rd[b]) || intersects(wr[b], rd[c]) || intersects(wr[b], wr[c]))) ok = false;
+                if (!ok) continue;
+                fh->pair = ht; ht->pair = fh;
+                g->nodes[a]->pair_leader = true;
                 break;
             }
         }

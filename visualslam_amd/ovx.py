@@ -268,8 +268,10 @@ def add_items(arr, items):
 
 def graph_fusions(graph):
     """what vxVerifyGraph fused (a debug export, not reference API): ColorConvert nodes converted inside the pyramid's first
-    launch, detector cell passes riding in the PyrLK launch, virtual grey images made views of a pyramid's level 0"""
-    buf = (C.c_int * 3)()
-    n = lib().visualslam_amd_graph_fusions(graph, buf, 3)
-    assert n == 3, "graph not verified"
-    return {"color_convert_in_pyramid": buf[0], "cells_in_pyrlk": buf[1], "virtual_gray_is_level0": buf[2]}
+    launch, detector cell passes riding in the PyrLK launch, virtual grey images made views of a pyramid's level 0,
+    FindHomography nodes sharing a launch with a detector node's merge pass"""
+    buf = (C.c_int * 4)()
+    n = lib().visualslam_amd_graph_fusions(graph, buf, 4)
+    assert n == 4, "graph not verified"
+    return {"color_convert_in_pyramid": buf[0], "cells_in_pyrlk": buf[1], "virtual_gray_is_level0": buf[2],
+            "merge_in_homography": buf[3]}

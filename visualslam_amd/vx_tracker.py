@@ -9,11 +9,13 @@ L = ovx.lib()
 class VxFeatureTracker:
     """call-for-call transcription of FeatureTrackerImpl (feature_tracker.cpp:127-449)"""
 
-    def __init__(self, ctx, p, w, h, first_frame, mask, homography=False, detect_on_copy=False):
+    def __init__(self, ctx, p, w, h, first_frame, mask, homography=False, detect_on_copy=False, homography_first=False):
         """homography=True appends the video stabilizer's / SFM sample's next stage to the same graph
         (demos/video_stabilizer/stabilizer.cpp:264-273): nvxFindHomographyNode on the PyrLK matches.
         detect_on_copy=True (tests): the detector reads a copy of the grey frame that an nvxCopyImageNode created AFTER the
-        PyrLK node makes, i.e. a graph in which the detector's input is not ready when PyrLK starts"""
+        PyrLK node makes, i.e. a graph in which the detector's input is not ready when PyrLK starts.
+        homography_first=True creates the FindHomography node BEFORE the detector node, the stabilizer's creation order
+        (stabilizer.cpp:266,299): it then precedes the detector node in the execution order"""
         self.ctx, self.p = ctx, p
         pex = L.vxCreatePyramid(ctx, p.pyr_levels, 0.5, w, h, ovx.VX_DF_IMAGE_U8)
         self.pyr_delay = L.vxCreateDelay(ctx, pex, 2)
@@ -33,6 +35,9 @@ class VxFeatureTracker:
                                            L.vxGetReferenceFromDelay(self.pts_delay, -1), L.vxGetReferenceFromDelay(self.pts_delay, -1),
                                            self.kp_curr, ovx.VX_TERM_CRITERIA_BOTH, eps, it, est, p.lk_win_size)
         out = L.vxGetReferenceFromDelay(self.pts_delay, 0)
+        self.hg = None
+        if homography and homography_first:
+            self._add_homography(ctx, p)
         det_in = gray
         if detect_on_copy:
             det_in = self.det_copy = L.vxCreateImage(ctx, w, h, ovx.VX_DF_IMAGE_U8)
@@ -42,13 +47,10 @@ class VxFeatureTracker:
             self.det = L.nvxHarrisTrackNode(self.g, det_in, out, mask, self.kp_curr, p.harris_k, p.harris_thresh, p.detector_cell_size, None)
         else:
             self.det = L.nvxFastTrackNode(self.g, det_in, out, mask, self.kp_curr, p.fast_type, p.fast_thresh, p.detector_cell_size, None)
-        self.hg = self.hg_matrix = self.hg_mask = None
-        if homography:
-            self.hg_matrix = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
-            self.hg_mask = L.vxCreateArray(ctx, ovx.VX_TYPE_UINT8, p.array_capacity)
-            self.hg = L.nvxFindHomographyNode(self.g, L.vxGetReferenceFromDelay(self.pts_delay, -1), self.kp_curr, self.hg_matrix,
-                                              ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, self.hg_mask)
-            assert L.vxGetStatus(self.hg) == ovx.VX_SUCCESS
+        if not homography:
+            self.hg = self.hg_matrix = self.hg_mask = None
+        if homography and not homography_first:
+            self._add_homography(ctx, p)
         for n in (self.cvt, self.pyr, self.lk, self.det):
             assert L.vxGetStatus(n) == ovx.VX_SUCCESS
         opt = b"-O3"
@@ -69,6 +71,17 @@ class VxFeatureTracker:
             ovx.check(L.nvxuFastTrack(ctx, fgray, L.vxGetReferenceFromDelay(self.pts_delay, 0), mask, None,
                                       p.fast_type, p.fast_thresh, p.detector_cell_size, None), "nvxuFastTrack")
         ovx.release("Image", fgray)
+
+    def _add_homography(self, ctx, p):
+        self.hg_matrix = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
+        self.hg_mask = L.vxCreateArray(ctx, ovx.VX_TYPE_UINT8, p.array_capacity)
+        import os
+        # experiment knobs (tools/exp_r3_hg_sweep.sh): hypothesis count through the confidence, refits; the defaults are the stabilizer's
+        conf = float(os.environ.get("VSA_EXP_HG_CONFIDENCE", "0.995"))
+        refine = int(os.environ.get("VSA_EXP_HG_REFINE", "10"))
+        self.hg = L.nvxFindHomographyNode(self.g, L.vxGetReferenceFromDelay(self.pts_delay, -1), self.kp_curr, self.hg_matrix,
+                                          ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, refine, conf, 0.45, self.hg_mask)
+        assert L.vxGetStatus(self.hg) == ovx.VX_SUCCESS
 
     def track(self, frame, mask, schedule_only=False):
         ovx.check(L.vxSetParameterByIndex(self.cvt, 0, frame))
