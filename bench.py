@@ -304,9 +304,7 @@ def main():
     if args.dry_run:
         dev = rank_device(local_rank, args.dry_run_devices or args.gpus)
         print(json.dumps({"rank": rank, "world": world, "device": dev, "streams": my_streams, "phases": phases,
-                          "preheat": {"seconds": args.preheat_s, "steps": preheat_steps,
-                        "note": "untimed set-up run of the same workload so that the GPU is at its operating clocks; the W warm-up steps follow"},
-            "host_cores": cores, "host_threads_total": len(my_streams) * world}), flush=True)
+                          "host_cores": cores, "host_threads_total": len(my_streams) * world}), flush=True)
         return
 
     import numpy as np

@@ -78,8 +78,7 @@ hipError_t launch_corner_cells(const CornerTrackParams &p, hipStream_t stream)
     if (p.detector == kHarris) {
         hipLaunchKernelGGL(k_harris_cells, dim3(blocks), dim3(64), lds, stream, a);
     } else {
-        const char *band_env = getenv("VSA_EXP_FS_BAND");      // experiment knob (tools/gpu_r3c.sh)
-        fast_cells_setup(p, a, blocks, lds, band_env ? atoi(band_env) : FS_BAND);
+        fast_cells_setup(p, a, blocks, lds, FS_BAND);
         switch (p.fast_n) {
         case 9: hipLaunchKernelGGL(k_fast_cells<9>, dim3(blocks), dim3(64), lds, stream, a); break;
         case 10: hipLaunchKernelGGL(k_fast_cells<10>, dim3(blocks), dim3(64), lds, stream, a); break;

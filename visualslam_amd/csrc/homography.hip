@@ -6,21 +6,25 @@
 // demos/video_stabilizer/homography_filter_node.cpp:36-159.  Semantics and the exact floating-point order:
 // oracle/vxoracle_homography.c -- results are bit-identical.
 //
-// One launch, no host round trip (k_find_homography):
+// One launch, no host round trip:
 //   * workgroup k evaluates hypothesis k (all hypotheses of the a-priori RANSAC count are independent, so they run as
 //     one batch): wave 0 draws the 4-point sample and maps it exactly in binary64 while the other waves fetch points;
 //     the workgroup then counts the hypothesis' inliers (binary32, division-free) and publishes count and matrix;
-//   * the workgroup that takes the last ticket (device-scope release / acquire) goes on with its points still in
-//     registers: it picks the best hypothesis, normalises coordinates, then alternates least-squares refits (29 binary64
-//     sums in 256 interleaved partials + butterfly, 8x8 LDL^T) with inlier recounts; writes matrix, mask and counts
-//     (also to pinned mirrors).
-// The work is tiny (56 x 4096 point tests): latency, not throughput, is what matters.  Hence
-//   * NPT > 0 variants, used when the arrays' capacities bound the point count by NPT*256: every point stays in
-//     registers for the whole kernel, and the loads do not wait for the item counts (NPT = 0: any size, global loads);
+//   * the workgroup that takes the last ticket goes on: it picks the best hypothesis, normalises coordinates, then alternates
+//     least-squares refits (29 binary64 sums in 256 interleaved partials + butterfly, 8x8 LDL^T) with inlier recounts; writes
+//     matrix, mask and counts (also to pinned mirrors).
+// The work is tiny (56 x 4096 point tests): latency is what matters to the caller -- and to the other camera streams on the GPU
+// the kernel's footprint, which decides whether its workgroups start beside their PyrLK waves or wait for them to drain.  Hence
+//   * k_find_homography_lean, used when the arrays' capacities bound the point count by 16 * 256 (the tracker graphs'): a thread's
+//     16 correspondences stay on chip for the whole kernel (destination points in registers, source points in LDS), the loads do
+//     not wait for the item counts, and the whole kernel fits in the 96 registers and 40 KB of LDS that four PyrLK waves per
+//     SIMD leave; k_find_homography (any size) re-reads the points from memory in every pass;
 //   * all sums of a pass go through ONE barrier pair: DPP butterfly inside each wave, four wave totals through LDS;
 //   * the serial binary64 parts (sample -> hypothesis, LDL^T, denormalisation) run on wave 0 with lanes as the
 //     parallel dimension: independent divisions share one instruction sequence, row i of the factorisation lives on
-//     lane i.  Every element still sees the operations of the sequential algorithm in the same order.
+//     lane i.  Every element still sees the operations of the sequential algorithm in the same order;
+//   * what the hypothesis workgroups hand to the refining one goes past the L2s word by word (device-scope relaxed atomics)
+//     instead of through a device-scope release / acquire, which on this GPU writes back and invalidates whole L2s.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -35,8 +39,10 @@ namespace {
 #ifdef VSA_HG_STAMPS   // development instrumentation: cycle stamps of the phases (thread 0 of workgroup 0)
 __device__ uint64_t g_hg_stamps[64];
 #define HG_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_hg_stamps[i] = clock64(); } while (0)
+#define HG_STAMP_ANY(i) do { if (threadIdx.x == 0) g_hg_stamps[i] = clock64(); } while (0)      // the one refining workgroup
 #else
 #define HG_STAMP(i) do { } while (0)
+#define HG_STAMP_ANY(i) do { } while (0)
 #endif
 
 constexpr int HG_T = 256;      // threads = interleaved partial sums (the oracle's HG_P)
@@ -281,33 +287,6 @@ __device__ __forceinline__ bool hg_make_hypothesis(const HgArgs &a, uint32_t k, 
     return true;
 }
 
-// The points of thread `tid`: NPT > 0 keeps points tid, tid + 256, ... in registers (the host guarantees
-// n <= NPT*256 <= the arrays' capacities, so the loads need not wait for the item counts); NPT == 0 reads global memory.
-template <int NPT>
-struct HgPoints {
-    float2 ps[NPT > 0 ? NPT : 1], pd[NPT > 0 ? NPT : 1];
-    uint32_t us;      // bit j: point j of this thread exists and is usable
-
-    __device__ __forceinline__ void fetch(const HgArgs &a, uint32_t bound)
-    {
-        if (NPT == 0) return;
-#pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            const uint32_t i = threadIdx.x + (uint32_t)j * HG_T;
-            ps[j] = pd[j] = make_float2(-1.0f, -1.0f);
-            if (i < bound) { ps[j] = a.src[i]; pd[j] = a.dst[i]; }
-        }
-    }
-    __device__ __forceinline__ void flag(uint32_t n)
-    {
-        us = 0;
-        if (NPT == 0) return;
-#pragma unroll
-        for (int j = 0; j < NPT; ++j)
-            us |= (threadIdx.x + (uint32_t)j * HG_T < n && hg_usable(ps[j], pd[j])) ? (1u << j) : 0u;
-    }
-};
-
 // index into the 29 sums of element (i, c), c <= i, of the normal-equation matrix (-1: zero)
 __host__ __device__ constexpr int hg_midx(int i, int c)
 {
@@ -401,10 +380,8 @@ __device__ __forceinline__ void hg_fit_publish(const double (&S)[HG_NACC], const
 }
 
 // Picks the best hypothesis, normalises, refits; one workgroup.  P: this thread's points, already fetched and flagged.
-template <int NPT>
-__device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uint32_t n)
+__device__ __forceinline__ void hg_refine(const HgArgs &a, uint32_t n)
 {
-    static_assert(NPT >= 0 && NPT <= 32, "one bit per point in a 32-bit mask");
     __shared__ double wsum[HG_NACC][4];
     __shared__ unsigned long long best_w[4];
     __shared__ uint32_t red[4];
@@ -426,9 +403,7 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
         best = key > best ? key : best;
     }
     uint32_t usable = 0;
-    if (NPT > 0) usable = __popc(P.us);
-    else
-        for (uint32_t i = tid; i < n; i += HG_T) usable += hg_usable(a.src[i], a.dst[i]) ? 1u : 0u;
+    for (uint32_t i = tid; i < n; i += HG_T) usable += hg_usable(a.src[i], a.dst[i]) ? 1u : 0u;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned long long o = __shfl_xor(best, off);
@@ -444,7 +419,7 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
     const uint32_t key = (uint32_t)(best >> 32), kbest = 0xffffffffu - (uint32_t)(best & 0xffffffffu);
 
     float H[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
-    uint32_t cnt = 0, inl = 0;
+    uint32_t cnt = 0;
     if (usable >= 4 && key >= 5) {      // a valid hypothesis with at least 4 inliers
         cnt = key - 1u;
 #pragma unroll
@@ -453,18 +428,10 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
 
         // normalisation over all usable correspondences (two passes, interleaved partials)
         double c4[4] = { 0, 0, 0, 0 };
-        if (NPT > 0) {
-#pragma unroll
-            for (int j = 0; j < NPT; ++j)
-                if ((P.us >> j) & 1u) {
-                    c4[0] += (double)P.ps[j].x; c4[1] += (double)P.ps[j].y; c4[2] += (double)P.pd[j].x; c4[3] += (double)P.pd[j].y;
-                }
-        } else {
-            for (uint32_t i = tid; i < n; i += HG_T) {
-                const float2 s = a.src[i], d = a.dst[i];
-                if (!hg_usable(s, d)) continue;
-                c4[0] += (double)s.x; c4[1] += (double)s.y; c4[2] += (double)d.x; c4[3] += (double)d.y;
-            }
+        for (uint32_t i = tid; i < n; i += HG_T) {
+            const float2 s = a.src[i], d = a.dst[i];
+            if (!hg_usable(s, d)) continue;
+            c4[0] += (double)s.x; c4[1] += (double)s.y; c4[2] += (double)d.x; c4[3] += (double)d.y;
         }
         block_tree_n<4>(c4, wsum);
         block_tree_read<4>(c4, wsum);
@@ -473,20 +440,11 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
         nm.cx = c4[0] / cntd; nm.cy = c4[1] / cntd; nm.cu = c4[2] / cntd; nm.cv = c4[3] / cntd;
         HG_STAMP(3);
         double d2[2] = { 0, 0 };
-        if (NPT > 0) {
-#pragma unroll
-            for (int j = 0; j < NPT; ++j)
-                if ((P.us >> j) & 1u) {
-                    d2[0] += fabs((double)P.ps[j].x - nm.cx) + fabs((double)P.ps[j].y - nm.cy);
-                    d2[1] += fabs((double)P.pd[j].x - nm.cu) + fabs((double)P.pd[j].y - nm.cv);
-                }
-        } else {
-            for (uint32_t i = tid; i < n; i += HG_T) {
-                const float2 s = a.src[i], d = a.dst[i];
-                if (!hg_usable(s, d)) continue;
-                d2[0] += fabs((double)s.x - nm.cx) + fabs((double)s.y - nm.cy);
-                d2[1] += fabs((double)d.x - nm.cu) + fabs((double)d.y - nm.cv);
-            }
+        for (uint32_t i = tid; i < n; i += HG_T) {
+            const float2 s = a.src[i], d = a.dst[i];
+            if (!hg_usable(s, d)) continue;
+            d2[0] += fabs((double)s.x - nm.cx) + fabs((double)s.y - nm.cy);
+            d2[1] += fabs((double)d.x - nm.cu) + fabs((double)d.y - nm.cv);
         }
         block_tree_n<2>(d2, wsum);
         block_tree_read<2>(d2, wsum);
@@ -495,10 +453,6 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
         nm.ss = norm_ok ? cntd / d2[0] : 0.0;
         nm.sd = norm_ok ? cntd / d2[1] : 0.0;
 
-        if (NPT > 0) {
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) inl |= (((P.us >> j) & 1u) & (uint32_t)hg_inlier(H, P.ps[j], P.pd[j], a.thr2)) << j;
-        }
         HG_STAMP(5);
 
         for (uint32_t r = 0; r < a.max_refine && norm_ok; ++r) {
@@ -521,23 +475,12 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
         ACC(27, q0, u); ACC(27, r0, v); ACC(28, q1, u); ACC(28, r1, v);                                                         \
     }
 #define ACC(k, p, q) acc[k] = fma(p, q, acc[k])
-            if (NPT > 0) {
-#pragma unroll
-                for (int j = 0; j < NPT; ++j) {
-                    if (!((inl >> j) & 1u)) continue;
-                    // opaque copies: keeps the compiler from hoisting every point's binary64 terms out of the refit
-                    // loop (they do not fit in registers next to the 29 sums)
-                    float sx = P.ps[j].x, sy = P.ps[j].y, dx = P.pd[j].x, dy = P.pd[j].y;
-                    asm volatile("" : "+v"(sx), "+v"(sy), "+v"(dx), "+v"(dy));
-                    HG_ACCUMULATE(sx, sy, dx, dy)
-                }
-            } else {
-                for (uint32_t i = tid; i < n; i += HG_T) {
-                    const float2 s = a.src[i], d = a.dst[i];
-                    if (!(hg_usable(s, d) && hg_inlier(H, s, d, a.thr2))) continue;
-                    HG_ACCUMULATE(s.x, s.y, d.x, d.y)
-                }
+            for (uint32_t i = tid; i < n; i += HG_T) {
+                const float2 s = a.src[i], d = a.dst[i];
+                if (!(hg_usable(s, d) && hg_inlier(H, s, d, a.thr2))) continue;
+                HG_ACCUMULATE(s.x, s.y, d.x, d.y)
             }
+
 #undef ACC
 #undef HG_ACCUMULATE
             HG_STAMP(9 + 6 * (r < 3 ? r : 3));
@@ -553,20 +496,13 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
             float Hn[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) Hn[i] = Hnew[i];
-            uint32_t is = 0, c = 0, diff = 0;
-            if (NPT > 0) {
-#pragma unroll
-                for (int j = 0; j < NPT; ++j) is |= (((P.us >> j) & 1u) & (uint32_t)hg_inlier(Hn, P.ps[j], P.pd[j], a.thr2)) << j;
-                c = __popc(is);
-                diff = __popc(is ^ inl);
-            } else {
-                for (uint32_t i = tid; i < n; i += HG_T) {
-                    const float2 s = a.src[i], d = a.dst[i];
-                    const bool us = hg_usable(s, d);
-                    const bool was = us && hg_inlier(H, s, d, a.thr2), now = us && hg_inlier(Hn, s, d, a.thr2);
-                    c += now ? 1u : 0u;
-                    diff += (was != now) ? 1u : 0u;
-                }
+            uint32_t c = 0, diff = 0;
+            for (uint32_t i = tid; i < n; i += HG_T) {
+                const float2 s = a.src[i], d = a.dst[i];
+                const bool us = hg_usable(s, d);
+                const bool was = us && hg_inlier(H, s, d, a.thr2), now = us && hg_inlier(Hn, s, d, a.thr2);
+                c += now ? 1u : 0u;
+                diff += (was != now) ? 1u : 0u;
             }
             c = block_sum_u32(c, red);
             diff = block_sum_u32(diff, red);
@@ -575,25 +511,17 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
 #pragma unroll
             for (int i = 0; i < 9; ++i) H[i] = Hn[i];
             cnt = c;
-            inl = is;
             if (diff == 0) break;
         }
     }
     HG_STAMP(6);
 
     if (a.mask) {
-        if (NPT > 0) {
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) {
-                const uint32_t i = tid + (uint32_t)j * HG_T;
-                if (i < n) a.mask[i] = (cnt != 0 && ((inl >> j) & 1u)) ? 255 : 0;
-            }
-        } else {
-            for (uint32_t i = tid; i < n; i += HG_T) {
-                const float2 s = a.src[i], d = a.dst[i];
-                a.mask[i] = (cnt != 0 && hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) ? 255 : 0;
-            }
+        for (uint32_t i = tid; i < n; i += HG_T) {
+            const float2 s = a.src[i], d = a.dst[i];
+            a.mask[i] = (cnt != 0 && hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) ? 255 : 0;
         }
+
     }
     if (tid < 9) {   // transposed on the way out (homography_filter_node.cpp:87-91)
         // (a chain of selects: indexed by the thread number the array would live in memory -- LDS, or scratch in the kernel
@@ -614,8 +542,7 @@ __device__ __forceinline__ void hg_refine(const HgArgs &a, HgPoints<NPT> &P, uin
 
 // One launch: workgroup k evaluates hypothesis k; the workgroup that publishes last (a ticket counter) goes on to
 // the refinement with its points still in registers.
-template <int NPT>
-__device__ __forceinline__ void find_homography_wg(const HgArgs &a, uint32_t bound, const uint32_t k)
+__device__ __forceinline__ void find_homography_wg(const HgArgs &a, const uint32_t k)
 {
     __shared__ float Hs[9];
     __shared__ int valid;
@@ -623,8 +550,6 @@ __device__ __forceinline__ void find_homography_wg(const HgArgs &a, uint32_t bou
     __shared__ uint32_t is_last;
     const uint32_t tid = threadIdx.x;
     HG_STAMP(32);
-    HgPoints<NPT> P;
-    P.fetch(a, bound);
     const uint32_t n = hg_n(a);
     HG_STAMP(33);
     if (tid < 64) {
@@ -633,7 +558,6 @@ __device__ __forceinline__ void find_homography_wg(const HgArgs &a, uint32_t bou
         if (tid < 9) Hs[tid] = ok ? e : (tid % 4u == 0u ? 1.0f : 0.0f);
         if (tid == 0) valid = ok ? 1 : 0;
     }
-    P.flag(n);
     HG_STAMP(34);
     __syncthreads();
     HG_STAMP(35);
@@ -642,15 +566,11 @@ __device__ __forceinline__ void find_homography_wg(const HgArgs &a, uint32_t bou
     for (int i = 0; i < 9; ++i) H[i] = Hs[i];
     uint32_t cnt = 0;
     if (valid) {
-        if (NPT > 0) {
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) cnt += (((P.us >> j) & 1u) & (uint32_t)hg_inlier(H, P.ps[j], P.pd[j], a.thr2));
-        } else {
-            for (uint32_t i = tid; i < n; i += HG_T) {
-                const float2 s = a.src[i], d = a.dst[i];
-                cnt += (hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) ? 1u : 0u;
-            }
+        for (uint32_t i = tid; i < n; i += HG_T) {
+            const float2 s = a.src[i], d = a.dst[i];
+            cnt += (hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) ? 1u : 0u;
         }
+
     }
     HG_STAMP(36);
     cnt = block_sum_u32(cnt, red);
@@ -675,20 +595,20 @@ __device__ __forceinline__ void find_homography_wg(const HgArgs &a, uint32_t bou
     if (!is_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler: nothing below moves above the ticket
     HG_STAMP(0);
-    hg_refine<NPT>(a, P, n);
+    hg_refine(a, n);
 }
 
-template <int NPT>
-__global__ __launch_bounds__(HG_T) void k_find_homography(HgArgs a, uint32_t bound)
+__global__ __launch_bounds__(HG_T) void k_find_homography(HgArgs a)
 {
-    find_homography_wg<NPT>(a, bound, blockIdx.x);
+    find_homography_wg(a, blockIdx.x);
 }
 
-// ---- the same algorithm in at most 96 registers (arrays of at most HG_NPT * 256 correspondences) -----------------------
-// What the register-resident kernel above costs the OTHER camera streams is its footprint, not its work: a workgroup of four
-// 298-register waves needs a compute unit whose four SIMDs each hold at most two PyrLK waves, so it waits for the other
-// streams' PyrLK launches to drain, and the four hardware queues fall into step -- a do-nothing kernel with that footprint takes
-// the 32-stream bench from 38.3 k to 30.3 k frames/s, the real work another 1.7 k (profiles/r03_homography_dummy_kernels.txt).
+// ---- the same algorithm with the points on chip, in at most 96 registers (arrays of at most HG_NPT * 256 correspondences) ----
+// Rounds 1 and 2 kept a thread's 16 correspondences in registers (298 in all, 19.8 us alone).  What that kernel cost the OTHER
+// camera streams was its footprint, not its work: a workgroup of four 298-register waves needs a compute unit whose four SIMDs
+// each hold at most two PyrLK waves, so it waits for the other streams' PyrLK launches to drain, and the four hardware queues fall
+// into step -- a do-nothing kernel with that footprint takes the 32-stream bench from 38.3 k to 30.3 k frames/s, the real work
+// another 1.7 k (profiles/r03_homography_dummy_kernels.txt).
 // Four PyrLK waves leave 96 registers per SIMD and 40 KB of LDS per compute unit; this form fits in them:
 //   * a thread's 16 correspondences: destination points in registers (32), source points in LDS (32 KB per workgroup, each thread
 //     reads back only what it wrote: no barrier);
@@ -868,6 +788,7 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
         best = o > best ? o : best;
         usable += __shfl_xor(usable, off);
     }
+    HG_STAMP_ANY(1);
     if (lane == 0) { L.best_w[wv] = best; L.red[wv] = usable; }
     __syncthreads();
 #pragma unroll
@@ -883,6 +804,7 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
     if (usable >= 4 && key >= 5) {      // a valid hypothesis with at least 4 inliers
         cnt = key - 1u;
         if (tid < 9) L.Hcur[tid] = pre ? L.hyp_s[9 * kbest + tid] : __hip_atomic_load(&hg_hyp(a)[9 * kbest + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        HG_STAMP_ANY(2);
         // normalisation over all usable correspondences (two passes, interleaved partials)
         double c4[4] = { 0, 0, 0, 0 };
 #pragma unroll
@@ -896,6 +818,7 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
         const double cntd = (double)usable;
         HgNorm nm;
         nm.cx = uniform64(c4[0] / cntd); nm.cy = uniform64(c4[1] / cntd); nm.cu = uniform64(c4[2] / cntd); nm.cv = uniform64(c4[3] / cntd);
+        HG_STAMP_ANY(3);
         double d2[2] = { 0, 0 };
 #pragma unroll
         for (int j = 0; j < HG_NPT; ++j)
@@ -906,6 +829,7 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
             }
         block_tree_n<2>(d2, L.wsum);
         block_tree_read<2>(d2, L.wsum);
+        HG_STAMP_ANY(4);
         const bool norm_ok = d2[0] > 0.0 && d2[1] > 0.0;
         nm.ss = uniform64(norm_ok ? cntd / d2[0] : 0.0);
         nm.sd = uniform64(norm_ok ? cntd / d2[1] : 0.0);
@@ -918,13 +842,18 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
                 us |= (((us >> j) & 1u) & (uint32_t)hg_inlier(H, L.src[tid + (uint32_t)j * HG_T], pd[j], a.thr2)) << (16 + j);
         }
 
+        HG_STAMP_ANY(5);
         for (uint32_t r = 0; r < a.max_refine && norm_ok; ++r) {
+            HG_STAMP_ANY(8 + 6 * (r < 3 ? r : 3));
             __syncthreads();      // the previous round's readers are done with the sums
             hg_refit_pass<0>(L, pd, us >> 16, nm, tid, lane, wv, L.wsum);
             hg_refit_pass<1>(L, pd, us >> 16, nm, tid, lane, wv, L.wsum);
             hg_refit_pass<2>(L, pd, us >> 16, nm, tid, lane, wv, L.wsum);
+            HG_STAMP_ANY(9 + 6 * (r < 3 ? r : 3));
             __syncthreads();
+            HG_STAMP_ANY(10 + 6 * (r < 3 ? r : 3));
             if (wv == 0) hg_fit_publish_lds(L.wsum, nm, lane, L.Hnew, &L.fit_ok);
+            HG_STAMP_ANY(12 + 6 * (r < 3 ? r : 3));
             __syncthreads();
             if (!L.fit_ok) break;     // block-uniform
             float Hn[9];
@@ -937,6 +866,7 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
             uint32_t c = __popc(is), diff = __popc(is ^ (us >> 16));
             c = block_sum_u32(c, L.red);
             diff = block_sum_u32(diff, L.red);
+            HG_STAMP_ANY(13 + 6 * (r < 3 ? r : 3));
             if (c < cnt) break;
             if (tid < 9) L.Hcur[tid] = L.Hnew[tid];     // (Hnew is next written after the next round's barriers)
             cnt = c;
@@ -944,6 +874,7 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
             if (diff == 0) break;
         }
     }
+    HG_STAMP_ANY(6);
     // (an opaque copy of the thread number for the write-out: the sixteen "i < n" lane masks, "tid < 9" and "tid == 0" would otherwise
     // be kept in scalar registers from the kernel's head to here)
     uint32_t t2 = tid;
@@ -963,6 +894,7 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
         a.matrix[t2] = v;
         if (a.matrix_host) a.matrix_host[t2] = v;
     }
+    HG_STAMP_ANY(7);
 }
 
 __device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_t bound, const uint32_t k)
@@ -975,6 +907,7 @@ __device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_
     };
     View L{ hg_src_points, Ls.wsum, Ls.best_w, Ls.hyp_s, Ls.Hs, Ls.Hnew, Ls.Hcur, Ls.red, Ls.valid, Ls.fit_ok, Ls.is_last };
     const uint32_t tid = threadIdx.x;
+    HG_STAMP(32);
     // The loads do not wait for the item counts: the host guarantees bound <= HG_NPT * HG_T <= the arrays' capacities.  Source points go
     // from memory straight into LDS (global_load_lds, 16 bytes = two points per lane, no registers in between); what lies at and
     // beyond `bound` is never read back (the usable test below starts with i < n <= bound).
@@ -997,14 +930,17 @@ __device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_
         if (i < bound) pd[j] = a.dst[i];
     }
     const uint32_t n = hg_n(a);
+    HG_STAMP(33);
     if (tid < 64) {
         float e;
         const bool ok = hg_make_hypothesis(a, k, n, tid, e);
         if (tid < 9) L.Hs[tid] = ok ? e : (tid % 4u == 0u ? 1.0f : 0.0f);
         if (tid == 0) L.valid = ok ? 1 : 0;
     }
+    HG_STAMP(34);
     __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): this wave's part of the source points is in LDS (the other waves': the barrier)
     __syncthreads();
+    HG_STAMP(35);
     float H[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) H[i] = L.Hs[i];
@@ -1019,6 +955,7 @@ __device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_
         us |= u << j;
         cnt += u & (uint32_t)hg_inlier(H, s, pd[j], a.thr2);
     }
+    HG_STAMP(36);
     cnt = block_sum_u32(valid ? cnt : 0u, L.red);
     // publish past the L2s, then take a ticket (see find_homography_wg)
     if (tid == 0) __hip_atomic_store(&hg_keys(a)[k], valid ? cnt + 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1032,8 +969,10 @@ __device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_
         if (t == a.K - 1u) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     __syncthreads();
+    HG_STAMP(37);
     if (!L.is_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    HG_STAMP_ANY(0);
     hg_refine_lean(a, L, pd, us, n);
 }
 
@@ -1042,12 +981,13 @@ __global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_f
 {
     find_homography_lean_wg(a, bound, blockIdx.x);
 }
+constexpr uint32_t HG_MERGE_KT = 8, HG_MERGE_KC = 13;   // rounds per block of the merge's walks (four waves, up to 96 registers)
 // ... and with a detector node's merge pass as workgroup 0 (k_find_homography_merge below is the any-size form)
 __global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_find_homography_lean_merge(HgArgs a, uint32_t bound, MergeArgs m)
 {
     if (blockIdx.x == 0) {
         VSA_SHORT_KERNEL_PRIORITY();
-        merge_compact_wg<(uint32_t)HG_T, 8u, 13u>(m);
+        merge_compact_wg<(uint32_t)HG_T, HG_MERGE_KT, HG_MERGE_KC>(m);
         return;
     }
     find_homography_lean_wg(a, bound, blockIdx.x - 1u);
@@ -1058,16 +998,14 @@ __global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_f
 // (merge_cells.hpp) and is long done when the refinement ends; workgroups 1 .. K are the hypotheses.  What a camera stream saves is
 // the merge's launch: its wait for a compute unit with room, its run and the gap in front of it, while the stream's hardware
 // queue is held by the homography's latency chain anyway.
-constexpr uint32_t HG_MERGE_KT = 8, HG_MERGE_KC = 13;   // rounds per block of the merge's walks: this kernel's register budget is the refit's
-template <int NPT>
-__global__ __launch_bounds__(HG_T) void k_find_homography_merge(HgArgs a, uint32_t bound, MergeArgs m)
+__global__ __launch_bounds__(HG_T) void k_find_homography_merge(HgArgs a, MergeArgs m)
 {
     if (blockIdx.x == 0) {
         VSA_SHORT_KERNEL_PRIORITY();
         merge_compact_wg<(uint32_t)HG_T, HG_MERGE_KT, HG_MERGE_KC>(m);
         return;
     }
-    find_homography_wg<NPT>(a, bound, blockIdx.x - 1u);
+    find_homography_wg(a, blockIdx.x - 1u);
 }
 
 }  // namespace
@@ -1114,7 +1052,7 @@ bool hg_setup(const HomographyParams &p, HgArgs &a, uint32_t &bound)
 bool hg_generic(uint32_t bound)
 {
     const bool force_generic = getenv("VISUALSLAM_AMD_HG_GENERIC") != nullptr;   // tests: exercise the any-size kernel
-    return bound > 16u * HG_T || force_generic;
+    return bound > (uint32_t)HG_NPT * HG_T || force_generic;
 }
 constexpr size_t HG_MERGE_MAX_LDS = 32u * 1024u;   // the merge's cell flags, beside the refinement's static arrays
 }  // namespace
@@ -1124,11 +1062,8 @@ hipError_t launch_find_homography(const HomographyParams &p, hipStream_t stream)
     HgArgs a{};
     uint32_t bound = 0;
     if (!hg_setup(p, a, bound)) return hipErrorInvalidValue;
-    if (!hg_generic(bound)) {
-        if (getenv("VSA_EXP_HG_FAT")) hipLaunchKernelGGL(k_find_homography<16>, dim3(p.hypotheses), dim3(HG_T), 0, stream, a, bound);
-        else hipLaunchKernelGGL(k_find_homography_lean, dim3(p.hypotheses), dim3(HG_T), HG_LEAN_DYN_LDS, stream, a, bound);
-    }
-    else hipLaunchKernelGGL(k_find_homography<0>, dim3(p.hypotheses), dim3(HG_T), 0, stream, a, bound);
+    if (!hg_generic(bound)) hipLaunchKernelGGL(k_find_homography_lean, dim3(p.hypotheses), dim3(HG_T), HG_LEAN_DYN_LDS, stream, a, bound);
+    else hipLaunchKernelGGL(k_find_homography, dim3(p.hypotheses), dim3(HG_T), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -1151,7 +1086,7 @@ hipError_t launch_find_homography_with_merge(const HomographyParams &p, const Co
     const dim3 grid(p.hypotheses + 1u);
     if (!hg_generic(bound))
         hipLaunchKernelGGL(k_find_homography_lean_merge, grid, dim3(HG_T), lds > HG_LEAN_DYN_LDS ? lds : HG_LEAN_DYN_LDS, stream, a, bound, m);
-    else hipLaunchKernelGGL(k_find_homography_merge<0>, grid, dim3(HG_T), lds, stream, a, bound, m);
+    else hipLaunchKernelGGL(k_find_homography_merge, grid, dim3(HG_T), lds, stream, a, m);
     return hipGetLastError();
 }
 

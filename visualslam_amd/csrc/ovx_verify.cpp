@@ -286,7 +286,7 @@ vx_status verify_graph(_vx_graph *g)
         // neither reads what the other writes, so they run as ONE launch (homography.hip) at the place of whichever comes first.
         // Legal when the later node can move up: it does not depend on the earlier one, and no node between the two writes what
         // it reads, or reads or writes what it writes.
-        for (size_t fi = 0; fi < n && getenv("VISUALSLAM_AMD_NO_FUSION") == nullptr && getenv("VSA_EXP_NO_PAIR") == nullptr; ++fi) {
+        for (size_t fi = 0; fi < n && getenv("VISUALSLAM_AMD_NO_FUSION") == nullptr; ++fi) {
             _vx_node *fh = g->nodes[fi];
             if (fh->kind != K_FIND_HOMOGRAPHY || fh->pair) continue;
             for (size_t hi = 0; hi < n; ++hi) {

@@ -75,12 +75,8 @@ class VxFeatureTracker:
     def _add_homography(self, ctx, p):
         self.hg_matrix = L.vxCreateMatrix(ctx, ovx.VX_TYPE_FLOAT32, 3, 3)
         self.hg_mask = L.vxCreateArray(ctx, ovx.VX_TYPE_UINT8, p.array_capacity)
-        import os
-        # experiment knobs (tools/exp_r3_hg_sweep.sh): hypothesis count through the confidence, refits; the defaults are the stabilizer's
-        conf = float(os.environ.get("VSA_EXP_HG_CONFIDENCE", "0.995"))
-        refine = int(os.environ.get("VSA_EXP_HG_REFINE", "10"))
         self.hg = L.nvxFindHomographyNode(self.g, L.vxGetReferenceFromDelay(self.pts_delay, -1), self.kp_curr, self.hg_matrix,
-                                          ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, refine, conf, 0.45, self.hg_mask)
+                                          ovx.NVX_FIND_HOMOGRAPHY_METHOD_RANSAC, 3.0, 2000, 10, 0.995, 0.45, self.hg_mask)
         assert L.vxGetStatus(self.hg) == ovx.VX_SUCCESS
 
     def track(self, frame, mask, schedule_only=False):
