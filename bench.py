@@ -541,7 +541,8 @@ def main():
                        "baseline_config": 4 if args.homography else cfg["baseline_config"], "frames": cfg["frames"],
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
                        "frame_ring": args.ring, "api": api_desc,
-                       "graph_stream_priority": os.environ["VISUALSLAM_AMD_STREAM_PRIORITY"] if args.api == "ovx" else None},
+                       "graph_stream_priority": os.environ["VISUALSLAM_AMD_STREAM_PRIORITY"] if args.api == "ovx" else None,
+                       "graph_fusions": ovx.graph_fusions(trackers[0].g) if args.api == "ovx" else None},
             "per_rank_frames_per_s": rank_fps,
             "repeat_frames_per_s": ({"median": float(np.median(rep_fps)), "min": min(rep_fps), "max": max(rep_fps), "blocks": len(rep_fps),
                                      "note": "the timed block run again back to back (same steps, barriers and synchronisation); "
