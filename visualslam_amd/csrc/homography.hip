@@ -1049,10 +1049,12 @@ bool hg_setup(const HomographyParams &p, HgArgs &a, uint32_t &bound)
     if (p.mask && p.mask_capacity < bound) bound = p.mask_capacity;
     return true;
 }
-bool hg_generic(uint32_t bound)
+// the any-size kernel: arrays that may hold more than HG_NPT * 256 correspondences, or a source array that is not 16-byte aligned
+// (the on-chip kernel fetches it in 16-byte pieces; arrays the runtime allocates always are)
+bool hg_generic(const HomographyParams &p, uint32_t bound)
 {
     const bool force_generic = getenv("VISUALSLAM_AMD_HG_GENERIC") != nullptr;   // tests: exercise the any-size kernel
-    return bound > (uint32_t)HG_NPT * HG_T || force_generic;
+    return bound > (uint32_t)HG_NPT * HG_T || (reinterpret_cast<uintptr_t>(p.src) & 15u) != 0 || force_generic;
 }
 constexpr size_t HG_MERGE_MAX_LDS = 32u * 1024u;   // the merge's cell flags, beside the refinement's static arrays
 }  // namespace
@@ -1062,7 +1064,7 @@ hipError_t launch_find_homography(const HomographyParams &p, hipStream_t stream)
     HgArgs a{};
     uint32_t bound = 0;
     if (!hg_setup(p, a, bound)) return hipErrorInvalidValue;
-    if (!hg_generic(bound)) hipLaunchKernelGGL(k_find_homography_lean, dim3(p.hypotheses), dim3(HG_T), HG_LEAN_DYN_LDS, stream, a, bound);
+    if (!hg_generic(p, bound)) hipLaunchKernelGGL(k_find_homography_lean, dim3(p.hypotheses), dim3(HG_T), HG_LEAN_DYN_LDS, stream, a, bound);
     else hipLaunchKernelGGL(k_find_homography, dim3(p.hypotheses), dim3(HG_T), 0, stream, a);
     return hipGetLastError();
 }
@@ -1084,7 +1086,7 @@ hipError_t launch_find_homography_with_merge(const HomographyParams &p, const Co
     size_t lds = 0;
     if (!hg_setup(p, a, bound) || !merge_setup(ct, m, lds) || lds > HG_MERGE_MAX_LDS) return hipErrorInvalidValue;
     const dim3 grid(p.hypotheses + 1u);
-    if (!hg_generic(bound))
+    if (!hg_generic(p, bound))
         hipLaunchKernelGGL(k_find_homography_lean_merge, grid, dim3(HG_T), lds > HG_LEAN_DYN_LDS ? lds : HG_LEAN_DYN_LDS, stream, a, bound, m);
     else hipLaunchKernelGGL(k_find_homography_merge, grid, dim3(HG_T), lds, stream, a, m);
     return hipGetLastError();
