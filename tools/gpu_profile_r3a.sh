@@ -13,12 +13,12 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
 tail -2 "$OUT/pytest_gpu.log"
 export TMPDIR=/tmp
 cd /tmp
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --repeats 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench.err"
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 100 --warmup 10 --no-cpu-baseline --repeats 0 --preheat-s 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench.err"
 cut -c1-200 "$OUT/bench_under_rocprof.json"
 python3 "$GRAFT_REPO_ROOT/tools/trace_timeline.py" "$(find "$OUT/bench" -name 'bench_kernel_trace.csv' | head -1)" > "$OUT/bench_concurrency.txt"
 cat "$OUT/bench_concurrency.txt"
 rm -f "$(find "$OUT/bench" -name 'bench_kernel_trace.csv' | head -1)"
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/single" -o single -- python3 "$GRAFT_REPO_ROOT/bench.py" --streams 1 --steps 300 --warmup 20 --no-cpu-baseline --repeats 0 > "$OUT/single_under_rocprof.json" 2> "$OUT/single.err"
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/single" -o single -- python3 "$GRAFT_REPO_ROOT/bench.py" --streams 1 --steps 300 --warmup 20 --no-cpu-baseline --repeats 0 --preheat-s 0 > "$OUT/single_under_rocprof.json" 2> "$OUT/single.err"
 cut -c1-200 "$OUT/single_under_rocprof.json"
 rm -f "$(find "$OUT/single" -name 'single_kernel_trace.csv' | head -1)"
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/thin" -o thin -- python3 "$GRAFT_REPO_ROOT/tools/prof_kernels.py" frame 200 > "$OUT/thin.log" 2>&1

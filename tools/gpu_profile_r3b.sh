@@ -20,11 +20,11 @@ cut -c1-200 "$OUT/bench_c2_2ranks_1gpu.json"
 export TMPDIR=/tmp
 cd /tmp
 for C in c1 c3; do
-  timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$C" -o $C -- python3 "$GRAFT_REPO_ROOT/bench.py" --config $C --steps 100 --warmup 10 --no-cpu-baseline --repeats 0 > "$OUT/${C}_under_rocprof.json" 2> "$OUT/$C.err"
+  timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$C" -o $C -- python3 "$GRAFT_REPO_ROOT/bench.py" --config $C --steps 100 --warmup 10 --no-cpu-baseline --repeats 0 --preheat-s 0 > "$OUT/${C}_under_rocprof.json" 2> "$OUT/$C.err"
   python3 "$GRAFT_REPO_ROOT/tools/trace_timeline.py" "$(find "$OUT/$C" -name "${C}_kernel_trace.csv" | head -1)" > "$OUT/${C}_concurrency.txt"
   rm -f "$(find "$OUT/$C" -name "${C}_kernel_trace.csv" | head -1)"
 done
-timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5" -o c5 -- python3 "$GRAFT_REPO_ROOT/bench.py" --homography --steps 100 --warmup 10 --no-cpu-baseline --repeats 0 > "$OUT/c5_under_rocprof.json" 2> "$OUT/c5.err"
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5" -o c5 -- python3 "$GRAFT_REPO_ROOT/bench.py" --homography --steps 100 --warmup 10 --no-cpu-baseline --repeats 0 --preheat-s 0 > "$OUT/c5_under_rocprof.json" 2> "$OUT/c5.err"
 python3 "$GRAFT_REPO_ROOT/tools/trace_timeline.py" "$(find "$OUT/c5" -name 'c5_kernel_trace.csv' | head -1)" > "$OUT/c5_concurrency.txt"
 rm -f "$(find "$OUT/c5" -name 'c5_kernel_trace.csv' | head -1)"
 cd "$GRAFT_REPO_ROOT"
