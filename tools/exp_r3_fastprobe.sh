@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-3 experiment: the VSA_EXP_* knobs it sets were taken out of the library again once the result was in; git log -S VSA_EXP_ finds the commits that had them)
 set -euo pipefail
 cd "$GRAFT_REPO_ROOT"
 for M in 0 1 2 4 6; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-3 experiment: the VSA_EXP_* knobs it sets were taken out of the library again once the result was in; git log -S VSA_EXP_ finds the commits that had them)
 # configs[4] with do-nothing stand-ins for the FindHomography kernel: (1) a few registers, (2) the real kernel's 298-register footprint
 set -euo pipefail
 cd "$GRAFT_REPO_ROOT"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-3 experiment: the VSA_EXP_* knobs it sets were taken out of the library again once the result was in; git log -S VSA_EXP_ finds the commits that had them)
 # What does the FindHomography node cost configs[4]?  Hypothesis count K (through the confidence; K workgroups of 4 waves x 298 registers)
 # and refits (the serial tail of the last workgroup), frames/s of bench.py --homography; VSA_EXP_NO_PAIR: merge pass in its own launch
 set -euo pipefail

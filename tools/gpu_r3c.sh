@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-3 experiment: the VSA_EXP_* knobs it sets were taken out of the library again once the result was in; git log -S VSA_EXP_ finds the commits that had them)
 # round 3, pass C: FAST pass with running minima -- parity, c3 bench, the kernel alone at band heights 18 / 36 / 54
 set -euo pipefail
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r3c

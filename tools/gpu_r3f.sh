@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-3 experiment: the VSA_EXP_* knobs it sets were taken out of the library again once the result was in; git log -S VSA_EXP_ finds the commits that had them)
 # round 3, pass F: configs[4] with the detector's merge pass inside the FindHomography launch against the two launches apart
 # (VSA_EXP_NO_PAIR), configs[1] for reference, then the whole GPU suite
 set -euo pipefail

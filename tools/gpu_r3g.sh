@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-3 experiment: the VSA_EXP_* knobs it sets were taken out of the library again once the result was in; git log -S VSA_EXP_ finds the commits that had them)
 # round 3, pass G: FindHomography's hand-over past the L2s (no device-scope release / acquire): homography tests incl. the 12-stream
 # one, configs[4] fused / apart, configs[1], then the whole GPU suite
 set -euo pipefail

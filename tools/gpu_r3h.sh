@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a round-3 experiment: the VSA_EXP_* knobs it sets were taken out of the library again once the result was in; git log -S VSA_EXP_ finds the commits that had them)
 # round 3, pass H: FindHomography in 96 registers (k_find_homography_lean): parity tests of everything with a homography in it, then
 # configs[4] lean / fat (VSA_EXP_HG_FAT) x pair fused / apart (VSA_EXP_NO_PAIR), kernel alone, then the whole GPU suite
 set -euo pipefail
