@@ -195,12 +195,13 @@ def host_cores():
 
 
 def default_streams(cfg, world, cores):
-    """Camera streams per GPU.  One GPU: the configuration's own count (32; 16 for 4K).  Several GPUs on one host: every stream has a
-    host thread that polls for its frame's end, so the ranks share the host's cores -- 8 streams already saturate a GPU
-    (profiles/r02_stream_sweep.txt: 4 -> 38.3 k, 8 -> 39.2 k, 32 -> 38.9 k frames/s), and 8 x 32 polling threads do not fit a host."""
-    if world <= 1:
-        return cfg["streams"]
-    return min(cfg["streams"], max(4, cores // world))
+    """Camera streams per GPU: a host core for every stream's thread, at most the configuration's own count (32; 16 for 4K), at least a
+    hardware queue each (4).  Every stream has a host thread that polls for its frame's end (hipStreamSynchronize spins), and 8 streams
+    already saturate a GPU (profiles/r03_stream_sweep.txt: 4 -> 39.1 k, 8 -> 39.7 k, 16 -> 39.4 k, 32 -> 37.6 k frames/s), so more threads
+    than cores buy nothing and cost a short run its steadiness: on the 16-core GPU box one driver-sized block in three reads 33-35 k
+    with 32 streams where 16 streams read 38.4-38.7 k every time (profiles/r03_streams_short_blocks.txt).  With several ranks on one
+    host the ranks share its cores."""
+    return min(cfg["streams"], max(4, cores // max(world, 1)))
 
 
 def launch_ranks(args, argv, poll_s=0.05):
@@ -255,7 +256,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 = BASELINE configs[1], the headline (default); c1 = configs[0] (640x480, demo ini); c3 = configs[2] (4K, FAST, 10k features)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="camera streams per GPU (default: 32; 16 for c3; with --gpus N > 1: min(that, max(4, host cores // N)))")
+                    help="camera streams per GPU (default: a host core per stream, min(32 (16 for c3), max(4, host cores // N)))")
     ap.add_argument("--ring", type=int, default=0, help="pre-generated frames resident in HBM (default: 64, SURVEY.md section 8d; 16 for c3)")
     ap.add_argument("--api", choices=["ovx", "thin"], default="ovx",
                     help="ovx: OpenVX graph API (default, the north-star path); thin: nvxcu primitives")
