@@ -51,7 +51,7 @@ def _read_matrix(m):
                                                     (37, 3.0, 3, 0.2, 0.2), (9000, 2.0, 4, 0.5, 0.35)])
 @pytest.mark.parametrize("large_array_kernels", [False, True])
 def test_immediate_matches_oracle(ctx, monkeypatch, n, thr, seed, noise, outl, large_array_kernels):
-    # arrays of capacity <= 4096 take the register-resident kernels; the switch forces the kernels for larger arrays
+    # arrays of capacity <= 4096 take the on-chip kernel (points in registers + LDS, 96 registers); the switch forces the any-size kernel
     if large_array_kernels:
         monkeypatch.setenv("VISUALSLAM_AMD_HG_GENERIC", "1")
     src, dst, _ = scene(n=n, noise=noise, outliers=outl, seed=seed)

@@ -610,8 +610,8 @@ __global__ __launch_bounds__(HG_T) void k_find_homography(HgArgs a)
 // into step -- a do-nothing kernel with that footprint takes the 32-stream bench from 38.3 k to 30.3 k frames/s, the real work
 // another 1.7 k (profiles/r03_homography_dummy_kernels.txt).
 // Four PyrLK waves leave 96 registers per SIMD and 40 KB of LDS per compute unit; this form fits in them:
-//   * a thread's 16 correspondences: destination points in registers (32), source points in LDS (32 KB per workgroup, each thread
-//     reads back only what it wrote: no barrier);
+//   * a thread's 16 correspondences: destination points in registers (32), source points in LDS (32 KB per workgroup, fetched
+//     straight into it, 16 bytes a lane; the barrier behind the hypothesis stands between those loads and the first read);
 //   * the refit's 29 binary64 sums in three passes over the inliers (10 + 10 + 9 sums; every sum still sees its products in the
 //     same order), one barrier pair for all three; the current matrix waits in LDS meanwhile;
 //   * the 8 x 8 solve reads the sums from LDS where it needs them (row i on lane i), keeps the pivots and the back-substituted
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(HG_T) void k_find_homography(HgArgs a)
 constexpr int HG_NPT = 16;
 static_assert(HG_NPT <= 16, "usable and inlier bits of a thread's points share one 32-bit register");
 
-// value of lane `src_lane` as a wave-uniform value the compiler keeps in scalar registers
+// a wave-uniform value, moved to scalar registers (the first lane's copy)
 __device__ __forceinline__ double uniform64(double v)
 {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
