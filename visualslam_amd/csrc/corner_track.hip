@@ -16,7 +16,8 @@
 //                        seven rows and their DPP-shifted copies (fast_cells.hpp).
 //   k_merge_compact      one workgroup marks cells that hold a surviving tracked point, then
 //                        compacts survivors (input order) and new corners (cell raster order)
-//                        with ballot/popcount prefix sums.
+//                        with ballot/popcount prefix sums (merge_cells.hpp; in a graph with a FindHomography
+//                        node on the same matches the pass is workgroup 0 of that node's launch, homography.hip).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -51,7 +51,10 @@ __device__ uint64_t g_mg_stamps[16];
 // in that hardware queue) held up meanwhile.  Eight waves of at most 48 VGPRs fit beside a full set of PyrLK waves (2 x 48 =
 // the 96 VGPRs they leave per SIMD): bench 28.4 k -> 30.8 k frames/s, single stream 12.2 k -> 12.0 k.  To stay at 48 VGPRs a wave
 // walks its range in small blocks and re-reads it for the write-out (L2 hits) instead of keeping it in registers
-// (a form that kept its ranges in registers between the counting pass and the write-out needed 96 VGPRs and lost 8 %).
+// (a form that kept its ranges in registers between the counting pass and the write-out needed 96 VGPRs and lost 8 %).  The budget is
+// tight enough for the register allocator's mood to matter (the same source as a function instead of a kernel body: 52, and the
+// 32-stream bench 17 % slower), so the one place where all 48 were in use -- the scan over the wave totals -- keeps its values in
+// scalar registers, and tests/test_kernel_resources.py reads the count from the built library.
 constexpr uint32_t MG_THREADS = 512;   // k_merge_compact's workgroup (the fused FindHomography + merge launch runs the pass on 4 waves)
 // rounds of 64 items per wave and block: tracked points / cells (1080p, cell 18: a wave owns 8 rounds of points, 13 of cells)
 constexpr uint32_t MG_KT = 4, MG_KC = 7;
@@ -149,8 +152,8 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t ballot)
 }
 
 // KT / KC: rounds of tracked points / cells per block of a walk (a block's loads are in flight together)
-// THREADS: workgroup size (a multiple of 64).  The launch's dynamic LDS is the cell flags, one byte per cell (a.flag_words words, at
-// least one) -- named here, not passed in: through a pointer argument the 8-wave kernel needs 52 registers instead of 48.
+// THREADS: workgroup size (a power-of-two number of waves).  The launch's dynamic LDS is the cell flags, one byte per cell
+// (a.flag_words words, at least one).
 template <uint32_t THREADS, uint32_t KT, uint32_t KC>
 __device__ __forceinline__ void merge_compact_wg(const MergeArgs a)
 {
