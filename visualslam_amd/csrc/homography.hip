@@ -143,6 +143,26 @@ __device__ __forceinline__ T wave_sum63(T v)
     return v;
 }
 
+// the largest of the 64 lanes' values, valid in lane 63 only (the moves of wave_sum63)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_max63(unsigned long long v)
+{
+    v = dpp_max<0xB1, 0xf>(v);
+    v = dpp_max<0x4E, 0xf>(v);
+    v = dpp_max<0x141, 0xf>(v);
+    v = dpp_max<0x140, 0xf>(v);
+    v = dpp_max<0x142, 0xa>(v);
+    v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
 // The butterfly over the 256 per-thread partials (offsets 1..128) for N sums at once, one barrier pair: offsets
 // 1..32 inside each wave, offsets 64 and 128 pair the four wave totals as (W0 + W1) + (W2 + W3).
 template <int N>
@@ -635,6 +655,70 @@ __device__ __forceinline__ void wave_total_to_lds(double v, double (*w)[4], int 
     if (lane == 63u) w[q][wv] = v;
 }
 
+// The same totals for several sums in ONE butterfly (the scheme of pyrlk.hip's wave_sum2/3, in binary64): after the step of
+// offset 1 a sum needs only every other lane, after offset 2 every fourth, so lanes l % 4 == 0..3 carry sums a..d from there
+// on.  The remaining steps must pair lanes of equal l % 4: rotations by 4 and 8 inside a row (canonical order in lanes
+// 12..15), then the row swaps, lane i of row r with lane i of row r ^ 1 and of row r ^ 2.  Every sum keeps the pairing of
+// wave_sum63 -- ((l0 + l1) + (l2 + l3)) per quad, (q0 + q1) + (q2 + q3) per row, (r0 + r1) + (r2 + r3) -- and binary64
+// addition commutes exactly, so the totals are the same bits.  Lanes 60..63 end with the totals of a..d.
+typedef unsigned hg_v2u __attribute__((ext_vector_type(2)));
+template <bool ROWS32>
+__device__ __forceinline__ double row_swap_sum(double z)
+{
+    const unsigned lo = (unsigned)__double2loint(z), hi = (unsigned)__double2hiint(z);
+    const hg_v2u l = ROWS32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const hg_v2u h = ROWS32 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)h.x, (int)l.x) + __hiloint2double((int)h.y, (int)l.y);
+}
+__device__ __forceinline__ double wave_sum_rows(double z)
+{
+    z = z + dpp_mov<0x124, 0xf>(z);   // row_ror:4
+    z = z + dpp_mov<0x128, 0xf>(z);   // row_ror:8
+    z = row_swap_sum<false>(z);       // rows 0,1: r0 + r1; rows 2,3: r2 + r3
+    return row_swap_sum<true>(z);     // (r0 + r1) + (r2 + r3) in every row
+}
+__device__ __forceinline__ double wave_sum_pair(double a, double b, bool lane_bit0)
+{
+    a = a + dpp_mov<0xB1, 0xf>(a);    // quad_perm [1,0,3,2]
+    b = b + dpp_mov<0xB1, 0xf>(b);
+    double z = lane_bit0 ? b : a;
+    z = z + dpp_mov<0x4E, 0xf>(z);    // quad_perm [2,3,0,1]: a partner of the same parity
+    return wave_sum_rows(z);          // a in lane 62, b in lane 63
+}
+__device__ __forceinline__ double wave_sum_quad(double a, double b, double c, double d, bool lane_bit0, bool lane_bit1)
+{
+    a = a + dpp_mov<0xB1, 0xf>(a);
+    b = b + dpp_mov<0xB1, 0xf>(b);
+    c = c + dpp_mov<0xB1, 0xf>(c);
+    d = d + dpp_mov<0xB1, 0xf>(d);
+    double y = lane_bit0 ? b : a, z = lane_bit0 ? d : c;
+    y = y + dpp_mov<0x4E, 0xf>(y);
+    z = z + dpp_mov<0x4E, 0xf>(z);
+    z = lane_bit1 ? z : y;            // lanes 0, 1 of a quad: a, b; lanes 2, 3: c, d
+    return wave_sum_rows(z);          // a..d in lanes 60..63
+}
+// wave totals of sums acc[0..N-1] into w[SUM[q]][wv]: quads, then a pair or a single one
+template <int N>
+__device__ __forceinline__ void wave_totals_to_lds(const double (&acc)[N], const int (&SUM)[10], double (*w)[4], uint32_t lane, uint32_t wv)
+{
+    asm volatile("" : "+v"(lane));    // (the lane-bit masks are made here, not kept in scalar registers across the kernel)
+    const bool b0 = lane & 1u, b1 = lane & 2u;
+    constexpr int Q = N / 4, R = N % 4;
+    static_assert(R != 3, "quads, then a pair or a single sum");
+#pragma unroll
+    for (int g = 0; g < Q; ++g) {
+        const double z = wave_sum_quad(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], b0, b1);
+        const int q = b1 ? (b0 ? SUM[4 * g + 3] : SUM[4 * g + 2]) : (b0 ? SUM[4 * g + 1] : SUM[4 * g]);
+        if (lane >= 60u) w[q][wv] = z;
+    }
+    if (R == 2) {
+        const double z = wave_sum_pair(acc[4 * Q], acc[4 * Q + 1], b0);
+        if (lane >= 62u) w[b0 ? SUM[4 * Q + 1] : SUM[4 * Q]][wv] = z;
+    } else if (R == 1) {
+        wave_total_to_lds(acc[4 * Q], w, SUM[4 * Q], lane, wv);
+    }
+}
+
 // hg_solve_lanes with the 29 sums read from LDS (w[q][0..3]: the four wave totals of sum q) by the lane that needs them
 __device__ __forceinline__ bool hg_solve_lanes_lds(const double (*w)[4], uint32_t lane, double (&h)[8])
 {
@@ -757,8 +841,7 @@ __device__ __forceinline__ void hg_refit_pass(const LDS &L, const float2 (&pd)[H
         }
 #undef ACC
     }
-#pragma unroll
-    for (int q = 0; q < N; ++q) wave_total_to_lds(acc[q], w, SUM[PASS][q], lane, wv);
+    wave_totals_to_lds<N>(acc, SUM[PASS], w, lane, wv);
     __builtin_amdgcn_sched_barrier(0);      // the passes one after the other: interleaved they would all hold their sums at once
 }
 
@@ -781,15 +864,10 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
         const unsigned long long key = ((unsigned long long)kk << 32) | (unsigned long long)(0xffffffffu - k);
         best = key > best ? key : best;
     }
-    uint32_t usable = __popc(us);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long o = __shfl_xor(best, off);
-        best = o > best ? o : best;
-        usable += __shfl_xor(usable, off);
-    }
+    uint32_t usable = wave_sum63((uint32_t)__popc(us));
+    best = wave_max63(best);
     HG_STAMP_ANY(1);
-    if (lane == 0) { L.best_w[wv] = best; L.red[wv] = usable; }
+    if (lane == 63u) { L.best_w[wv] = best; L.red[wv] = usable; }
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < 4; ++w) best = L.best_w[w] > best ? L.best_w[w] : best;
@@ -808,11 +886,10 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
         // normalisation over all usable correspondences (two passes, interleaved partials)
         double c4[4] = { 0, 0, 0, 0 };
 #pragma unroll
-        for (int j = 0; j < HG_NPT; ++j)
-            if ((us >> j) & 1u) {
-                const float2 s = L.src[tid + (uint32_t)j * HG_T];
-                c4[0] += (double)s.x; c4[1] += (double)s.y; c4[2] += (double)pd[j].x; c4[3] += (double)pd[j].y;
-            }
+        for (int j = 0; j < HG_NPT; ++j) {
+            const float2 s = L.src[tid + (uint32_t)j * HG_T];      // (read whether used or not: the reads go out together)
+            if ((us >> j) & 1u) { c4[0] += (double)s.x; c4[1] += (double)s.y; c4[2] += (double)pd[j].x; c4[3] += (double)pd[j].y; }
+        }
         block_tree_n<4>(c4, L.wsum);
         block_tree_read<4>(c4, L.wsum);
         const double cntd = (double)usable;
@@ -821,12 +898,13 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
         HG_STAMP_ANY(3);
         double d2[2] = { 0, 0 };
 #pragma unroll
-        for (int j = 0; j < HG_NPT; ++j)
+        for (int j = 0; j < HG_NPT; ++j) {
+            const float2 s = L.src[tid + (uint32_t)j * HG_T];
             if ((us >> j) & 1u) {
-                const float2 s = L.src[tid + (uint32_t)j * HG_T];
                 d2[0] += fabs((double)s.x - nm.cx) + fabs((double)s.y - nm.cy);
                 d2[1] += fabs((double)pd[j].x - nm.cu) + fabs((double)pd[j].y - nm.cv);
             }
+        }
         block_tree_n<2>(d2, L.wsum);
         block_tree_read<2>(d2, L.wsum);
         HG_STAMP_ANY(4);
@@ -864,8 +942,9 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
             for (int j = 0; j < HG_NPT; ++j)
                 is |= (((us >> j) & 1u) & (uint32_t)hg_inlier(Hn, L.src[tid + (uint32_t)j * HG_T], pd[j], a.thr2)) << j;
             uint32_t c = __popc(is), diff = __popc(is ^ (us >> 16));
-            c = block_sum_u32(c, L.red);
-            diff = block_sum_u32(diff, L.red);
+            c = block_sum_u32(c | (diff << 16), L.red);     // both counts are at most 4096: one sum, 16 bits each
+            diff = c >> 16;
+            c &= 0xffffu;
             HG_STAMP_ANY(13 + 6 * (r < 3 ? r : 3));
             if (c < cnt) break;
             if (tid < 9) L.Hcur[tid] = L.Hnew[tid];     // (Hnew is next written after the next round's barriers)
@@ -951,7 +1030,7 @@ __device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_
 #pragma unroll
     for (int j = 0; j < HG_NPT; ++j) {
         const float2 s = L.src[t1 + (uint32_t)j * HG_T];
-        const uint32_t u = (t1 + (uint32_t)j * HG_T < n && hg_usable(s, pd[j])) ? 1u : 0u;
+        const uint32_t u = (uint32_t)(t1 + (uint32_t)j * HG_T < n) & (uint32_t)hg_usable(s, pd[j]);     // (no branch: the sixteen reads go out together)
         us |= u << j;
         cnt += u & (uint32_t)hg_inlier(H, s, pd[j], a.thr2);
     }
