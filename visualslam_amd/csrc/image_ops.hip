@@ -415,11 +415,16 @@ hipError_t launch_pyramid_levels(const PyramidView &pyr, const ImageView *rgbx, 
         if (from_rgbx) hipLaunchKernelGGL((k_pyramid_fused<NS_, T_, true>), grid, dim3(PYR_THREADS), 0, stream, a);                   \
         else hipLaunchKernelGGL((k_pyramid_fused<NS_, T_, false>), grid, dim3(PYR_THREADS), 0, stream, a);                            \
     } while (0)
+        // Frames up to 640 x 480 (BASELINE configs[0]): a camera stream's launches are a chain of latencies on a GPU with room to
+        // spare, and half-size top tiles shorten a workgroup's chain of steps and barriers while the extra halo work finds idle
+        // compute units: 83.3 k against 80.6 k frames/s.  At 1080p the GPU is busy and the same choice for the launches with
+        // fewer workgroups than compute units costs 1.5 % (configs[4]: 3 %), profiles/r03_kernel_experiments.txt.
+        const bool small_frame = (uint64_t)pyr.width[0] * pyr.height[0] <= 640u * 480u;
         switch (ns) {
-        case 1: VSA_PYR_LAUNCH(1, 32); break;
+        case 1: if (small_frame) VSA_PYR_LAUNCH(1, 16); else VSA_PYR_LAUNCH(1, 32); break;
         case 2: VSA_PYR_LAUNCH(2, 16); break;
         case 3: VSA_PYR_LAUNCH(3, 8); break;
-        default: VSA_PYR_LAUNCH(4, 4); break;
+        default: if (small_frame) VSA_PYR_LAUNCH(4, 2); else VSA_PYR_LAUNCH(4, 4); break;
         }
 #undef VSA_PYR_LAUNCH
         hipError_t e = hipGetLastError();
