@@ -394,7 +394,7 @@ def test_native_host_threads_drive_streams_like_the_python_loop(ctx):
 
 
 @pytest.mark.parametrize("w,h,levels", [(640, 480, 6), (643, 481, 5), (1920, 1080, 5), (3840, 2160, 7), (37, 29, 3), (130, 70, 2),
-                                        (5, 3, 2), (64, 64, 1)])
+                                        (5, 3, 2), (64, 64, 1), (333, 241, 6), (639, 479, 5)])
 @pytest.mark.parametrize("fusion", [True, False])
 def test_color_convert_and_pyramid_nodes_fused_or_not(gpu, monkeypatch, w, h, levels, fusion):
     """vxVerifyGraph fuses ColorConvert(frame -> level 0) with GaussianPyramid(level 0 -> pyramid) into one launch that reads
