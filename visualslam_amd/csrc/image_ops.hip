@@ -390,7 +390,11 @@ hipError_t launch_pyramid_levels(const PyramidView &pyr, const ImageView *rgbx, 
 {
     uint32_t lvl = 0;
     while (lvl + 1 < pyr.levels) {
-        uint32_t ns = (pyr.levels - 1 - lvl) < 4u ? (pyr.levels - 1 - lvl) : 4u;
+        // More than four steps left: the launch on the LARGER level takes the fewer steps -- a tile's source region grows with the
+        // steps under it (67, 73, 85, 109 pixels a side for 64 owned), and that halo is paid on every pixel of the launch's source
+        // level.  Five steps as 2 + 3 read 1.4 times the larger level, as 4 + 1 they read 2.9 times (4K / 7 levels: +1.2 %).
+        const uint32_t left = pyr.levels - 1 - lvl;
+        uint32_t ns = left <= 4u ? left : (left <= 8u ? (left - 4u > 2u ? left - 4u : 2u) : 4u);
         PyrFusedArgs a{};
         a.src = pyr.ptr[lvl]; a.src_pitch = pyr.pitch[lvl];
         a.sw = (int)pyr.width[lvl]; a.sh = (int)pyr.height[lvl];
