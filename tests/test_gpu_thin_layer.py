@@ -56,7 +56,8 @@ def test_color_convert_rejects_bad_args(gpu):
 # --------------------------------------------------------------------------- Gaussian pyramid
 @pytest.mark.parametrize("w,h,levels", [(640, 480, 6), (1920, 1080, 5), (3840, 2160, 7), (65, 33, 4),
                                         (5, 7, 3), (131, 35, 2), (1, 1, 3),
-                                        (333, 241, 5), (331, 243, 2), (1283, 721, 5)])   # odd borders of the small frames' half-size tiles (and of the large ones)
+                                        (333, 241, 5), (331, 243, 2), (1283, 721, 5),
+                                        (1024, 768, 10), (701, 501, 8), (643, 487, 6)])   # odd borders of the small frames' half-size tiles (and of the large ones)
 def test_gaussian_pyramid_bit_exact(gpu, w, h, levels):
     rng = np.random.default_rng(w + h + levels)
     gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
