@@ -97,11 +97,12 @@ def test_short_kernels_fit_beside_four_pyrlk_waves(kernels):
 
 
 def test_find_homography_fits_beside_four_pyrlk_waves(kernels):
-    """the kernel the graphs run (arrays of up to 4096 correspondences), alone and with a detector's merge pass as workgroup 0: one
-    wave per SIMD in the 96 registers four PyrLK waves leave, its 32 KB of points in dynamic LDS (homography.hip: declared
-    statically the compiler rounds the register count up to 97 = 104 allocated, and a 298-register form cost the 32-stream
-    configs[4] bench a quarter of its frame rate, profiles/r03_homography_dummy_kernels.txt)"""
-    for n in ("k_find_homography_lean", "k_find_homography_lean_merge"):
+    """the kernel the graphs run (arrays of up to 4096 correspondences) and the one for arrays of any size, alone and with a
+    detector's merge pass as workgroup 0: one wave per SIMD in the 96 registers four PyrLK waves leave, the on-chip kernel's 32 KB
+    of points in dynamic LDS (homography.hip: declared statically the compiler rounds the register count up to 97 = 104
+    allocated, and a 298-register form cost the 32-stream configs[4] bench a quarter of its frame rate,
+    profiles/r03_homography_dummy_kernels.txt)"""
+    for n in ("k_find_homography_lean", "k_find_homography_lean_merge", "k_find_homography", "k_find_homography_merge"):
         k = kernels[n]
         assert _regs(k) <= 96, (n, _regs(k))
         assert int(k[".group_segment_fixed_size"]) <= 8 * 1024, (n, k[".group_segment_fixed_size"])

@@ -15,10 +15,11 @@
 //     matrix, mask and counts (also to pinned mirrors).
 // The work is tiny (56 x 4096 point tests): latency is what matters to the caller -- and to the other camera streams on the GPU
 // the kernel's footprint, which decides whether its workgroups start beside their PyrLK waves or wait for them to drain.  Hence
-//   * k_find_homography_lean, used when the arrays' capacities bound the point count by 16 * 256 (the tracker graphs'): a thread's
-//     16 correspondences stay on chip for the whole kernel (destination points in registers, source points in LDS), the loads do
-//     not wait for the item counts, and the whole kernel fits in the 96 registers and 40 KB of LDS that four PyrLK waves per
-//     SIMD leave; k_find_homography (any size) re-reads the points from memory in every pass;
+//   * both kernels fit in the 96 registers and 40 KB of LDS that four PyrLK waves per SIMD leave (the refit's sums in three passes,
+//     the solve reading them from LDS).  k_find_homography_lean, used when the arrays' capacities bound the point count by
+//     16 * 256 (the tracker graphs'): a thread's 16 correspondences stay on chip for the whole kernel (destination points in
+//     registers, source points in LDS) and the loads do not wait for the item counts; k_find_homography (any size) streams the
+//     points from memory in every pass, four per thread in flight;
 //   * all sums of a pass go through ONE barrier pair: DPP butterfly inside each wave, four wave totals through LDS;
 //   * the serial binary64 parts (sample -> hypothesis, LDL^T, denormalisation) run on wave 0 with lanes as the
 //     parallel dimension: independent divisions share one instruction sequence, row i of the factorisation lives on
@@ -321,322 +322,24 @@ static_assert(hg_midx(0, 0) == 0 && hg_midx(1, 0) == 1 && hg_midx(2, 0) == 2 && 
               hg_midx(7, 0) == 7 && hg_midx(6, 2) == 10 && hg_midx(7, 5) == 17 && hg_midx(6, 3) == 12 && hg_midx(6, 6) == 18 &&
               hg_midx(7, 6) == 19 && hg_midx(7, 7) == 20, "normal-equation layout");
 
-// LDL^T solve of the 8x8 normal equations on lanes 0..7 of one wave: lane i owns row i of M and of L; every element
-// sees exactly the operations of the sequential algorithm (oracle/vxoracle_homography.c, hg_fit), in the same order.
-__device__ __forceinline__ bool hg_solve_lanes(const double (&S)[HG_NACC], uint32_t lane, double (&h)[8])
-{
-    double Mrow[8], Lrow[8], LT[8], D[8], brow = 0.0, Dself = 1.0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { Mrow[c] = 0.0; Lrow[c] = 0.0; LT[c] = 0.0; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (lane == (uint32_t)i) {
-#pragma unroll
-            for (int c = 0; c <= i; ++c) Mrow[c] = hg_midx(i, c) >= 0 ? S[hg_midx(i, c) >= 0 ? hg_midx(i, c) : 0] : 0.0;
-            brow = S[21 + i];
-        }
-    bool pd = true;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        double t = Mrow[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) t -= (Lrow[k] * lane_bcast(Lrow[k], j)) * D[k];
-        const double d = lane_bcast(t, j);
-        pd = pd && (d > 1e-12);
-        D[j] = d;
-        const double l = t / d;
-        Lrow[j] = lane > (uint32_t)j ? l : 0.0;
-        if (lane == (uint32_t)j) Dself = d;
-#pragma unroll
-        for (int i = j + 1; i < 8; ++i) {
-            const double c = lane_bcast(l, i);
-            if (lane == (uint32_t)j) LT[i] = c;
-        }
-    }
-    double z = brow;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const double zk = lane_bcast(z, k);
-        if (lane > (uint32_t)k) z -= Lrow[k] * zk;
-    }
-    const double s0 = z / Dself;
-#pragma unroll
-    for (int i = 7; i >= 0; --i) {
-        double r = s0;
-#pragma unroll
-        for (int k = i + 1; k < 8; ++k) r -= LT[k] * h[k];
-        h[i] = lane_bcast(r, i);
-    }
-    return pd;
-}
-
 struct HgNorm { double cx, cy, cu, cv, ss, sd; };
 
-// wave 0, all lanes: the 29 sums -> least-squares H (h22 = 1), denormalised, rounded to binary32, published in LDS
-__device__ __forceinline__ void hg_fit_publish(const double (&S)[HG_NACC], const HgNorm &nm, uint32_t lane, float *Hnew, int *fit_ok)
-{
-    double h[8];
-    bool ok = hg_solve_lanes(S, lane, h);
-    const double Hn[9] = { h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 1.0 };
-    double G[9], Hd[9];
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
-        G[3 * rr] = Hn[3 * rr] * nm.ss;
-        G[3 * rr + 1] = Hn[3 * rr + 1] * nm.ss;
-        G[3 * rr + 2] = (Hn[3 * rr + 2] - G[3 * rr] * nm.cx) - G[3 * rr + 1] * nm.cy;
-    }
-    const double g6[6] = { G[0], G[1], G[2], G[3], G[4], G[5] };
-    const double gq = lane_select<6>(g6, lane) / nm.sd;      // G[c] / sd, c = 0..5, in one division
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        Hd[c] = lane_bcast(gq, c) + nm.cu * G[6 + c];
-        Hd[3 + c] = lane_bcast(gq, 3 + c) + nm.cv * G[6 + c];
-        Hd[6 + c] = G[6 + c];
-    }
-    float e;
-    ok = hg_to_f32_lanes(Hd, lane, e) && ok;
-    if (lane < 9) Hnew[lane] = ok ? e : (lane % 4u == 0u ? 1.0f : 0.0f);
-    if (lane == 0) *fit_ok = ok ? 1 : 0;
-}
-
-// Picks the best hypothesis, normalises, refits; one workgroup.  P: this thread's points, already fetched and flagged.
-__device__ __forceinline__ void hg_refine(const HgArgs &a, uint32_t n)
-{
-    __shared__ double wsum[HG_NACC][4];
-    __shared__ unsigned long long best_w[4];
-    __shared__ uint32_t red[4];
-    __shared__ float Hnew[9];
-    __shared__ int fit_ok;
-    __shared__ float hyp_s[HG_KPRE * 9];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-
-    // all hypotheses travel with the keys, so the winner's matrix is not one more dependent trip to memory
-    const bool pre = a.K <= (uint32_t)HG_KPRE;
-    // (keys and hypotheses were published by workgroups on other XCDs: read past this XCD's L2, see find_homography_wg)
-    if (pre)
-        for (uint32_t e = tid; e < 9u * a.K; e += HG_T) hyp_s[e] = __hip_atomic_load(&hg_hyp(a)[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // best hypothesis: most inliers, ties to the lowest index
-    unsigned long long best = 0;
-    for (uint32_t k = tid; k < a.K; k += HG_T) {
-        const uint32_t kk = __hip_atomic_load(&hg_keys(a)[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long key = ((unsigned long long)kk << 32) | (unsigned long long)(0xffffffffu - k);
-        best = key > best ? key : best;
-    }
-    uint32_t usable = 0;
-    for (uint32_t i = tid; i < n; i += HG_T) usable += hg_usable(a.src[i], a.dst[i]) ? 1u : 0u;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long o = __shfl_xor(best, off);
-        best = o > best ? o : best;
-        usable += __shfl_xor(usable, off);
-    }
-    HG_STAMP(1);
-    if (lane == 0) { best_w[wv] = best; red[wv] = usable; }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 4; ++w) best = best_w[w] > best ? best_w[w] : best;
-    usable = red[0] + red[1] + red[2] + red[3];
-    const uint32_t key = (uint32_t)(best >> 32), kbest = 0xffffffffu - (uint32_t)(best & 0xffffffffu);
-
-    float H[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
-    uint32_t cnt = 0;
-    if (usable >= 4 && key >= 5) {      // a valid hypothesis with at least 4 inliers
-        cnt = key - 1u;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) H[i] = pre ? hyp_s[9 * kbest + i] : __hip_atomic_load(&hg_hyp(a)[9 * kbest + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        HG_STAMP(2);
-
-        // normalisation over all usable correspondences (two passes, interleaved partials)
-        double c4[4] = { 0, 0, 0, 0 };
-        for (uint32_t i = tid; i < n; i += HG_T) {
-            const float2 s = a.src[i], d = a.dst[i];
-            if (!hg_usable(s, d)) continue;
-            c4[0] += (double)s.x; c4[1] += (double)s.y; c4[2] += (double)d.x; c4[3] += (double)d.y;
-        }
-        block_tree_n<4>(c4, wsum);
-        block_tree_read<4>(c4, wsum);
-        const double cntd = (double)usable;
-        HgNorm nm;
-        nm.cx = c4[0] / cntd; nm.cy = c4[1] / cntd; nm.cu = c4[2] / cntd; nm.cv = c4[3] / cntd;
-        HG_STAMP(3);
-        double d2[2] = { 0, 0 };
-        for (uint32_t i = tid; i < n; i += HG_T) {
-            const float2 s = a.src[i], d = a.dst[i];
-            if (!hg_usable(s, d)) continue;
-            d2[0] += fabs((double)s.x - nm.cx) + fabs((double)s.y - nm.cy);
-            d2[1] += fabs((double)d.x - nm.cu) + fabs((double)d.y - nm.cv);
-        }
-        block_tree_n<2>(d2, wsum);
-        block_tree_read<2>(d2, wsum);
-        HG_STAMP(4);
-        const bool norm_ok = d2[0] > 0.0 && d2[1] > 0.0;
-        nm.ss = norm_ok ? cntd / d2[0] : 0.0;
-        nm.sd = norm_ok ? cntd / d2[1] : 0.0;
-
-        HG_STAMP(5);
-
-        for (uint32_t r = 0; r < a.max_refine && norm_ok; ++r) {
-            HG_STAMP(8 + 6 * (r < 3 ? r : 3));
-            // least-squares refit over the inliers of H
-            double acc[HG_NACC];
-#pragma unroll
-            for (int q = 0; q < HG_NACC; ++q) acc[q] = 0.0;
-#define HG_ACCUMULATE(sx, sy, dx, dy)                                                                                          \
-    {                                                                                                                          \
-        const double x = ((double)(sx) - nm.cx) * nm.ss, y = ((double)(sy) - nm.cy) * nm.ss;                                    \
-        const double u = ((double)(dx) - nm.cu) * nm.sd, v = ((double)(dy) - nm.cv) * nm.sd;                                    \
-        const double q0 = -(x * u), q1 = -(y * u), r0 = -(x * v), r1 = -(y * v);                                                \
-        ACC(0, x, x); ACC(1, x, y); ACC(2, x, 1.0); ACC(3, y, y); ACC(4, y, 1.0); ACC(5, 1.0, 1.0);                              \
-        ACC(6, x, q0); ACC(7, x, q1); ACC(8, y, q0); ACC(9, y, q1); ACC(10, 1.0, q0); ACC(11, 1.0, q1);                          \
-        ACC(12, x, r0); ACC(13, x, r1); ACC(14, y, r0); ACC(15, y, r1); ACC(16, 1.0, r0); ACC(17, 1.0, r1);                      \
-        ACC(18, q0, q0); ACC(18, r0, r0); ACC(19, q0, q1); ACC(19, r0, r1); ACC(20, q1, q1); ACC(20, r1, r1);                    \
-        ACC(21, x, u); ACC(22, y, u); ACC(23, 1.0, u);                                                                         \
-        ACC(24, x, v); ACC(25, y, v); ACC(26, 1.0, v);                                                                         \
-        ACC(27, q0, u); ACC(27, r0, v); ACC(28, q1, u); ACC(28, r1, v);                                                         \
-    }
-#define ACC(k, p, q) acc[k] = fma(p, q, acc[k])
-            for (uint32_t i = tid; i < n; i += HG_T) {
-                const float2 s = a.src[i], d = a.dst[i];
-                if (!(hg_usable(s, d) && hg_inlier(H, s, d, a.thr2))) continue;
-                HG_ACCUMULATE(s.x, s.y, d.x, d.y)
-            }
-
-#undef ACC
-#undef HG_ACCUMULATE
-            HG_STAMP(9 + 6 * (r < 3 ? r : 3));
-            block_tree_n<HG_NACC>(acc, wsum);
-            HG_STAMP(10 + 6 * (r < 3 ? r : 3));
-            if (wv == 0) {
-                block_tree_read<HG_NACC>(acc, wsum);
-                hg_fit_publish(acc, nm, lane, Hnew, &fit_ok);
-            }
-            HG_STAMP(12 + 6 * (r < 3 ? r : 3));
-            __syncthreads();
-            if (!fit_ok) break;     // block-uniform
-            float Hn[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Hn[i] = Hnew[i];
-            uint32_t c = 0, diff = 0;
-            for (uint32_t i = tid; i < n; i += HG_T) {
-                const float2 s = a.src[i], d = a.dst[i];
-                const bool us = hg_usable(s, d);
-                const bool was = us && hg_inlier(H, s, d, a.thr2), now = us && hg_inlier(Hn, s, d, a.thr2);
-                c += now ? 1u : 0u;
-                diff += (was != now) ? 1u : 0u;
-            }
-            c = block_sum_u32(c, red);
-            diff = block_sum_u32(diff, red);
-            HG_STAMP(13 + 6 * (r < 3 ? r : 3));
-            if (c < cnt) break;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) H[i] = Hn[i];
-            cnt = c;
-            if (diff == 0) break;
-        }
-    }
-    HG_STAMP(6);
-
-    if (a.mask) {
-        for (uint32_t i = tid; i < n; i += HG_T) {
-            const float2 s = a.src[i], d = a.dst[i];
-            a.mask[i] = (cnt != 0 && hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) ? 255 : 0;
-        }
-
-    }
-    if (tid < 9) {   // transposed on the way out (homography_filter_node.cpp:87-91)
-        // (a chain of selects: indexed by the thread number the array would live in memory -- LDS, or scratch in the kernel
-        // that also has dynamic LDS -- for the whole refinement)
-        const uint32_t e = 3u * (tid % 3u) + tid / 3u;
-        float v = H[0];
-#pragma unroll
-        for (int i = 1; i < 9; ++i) v = e == (uint32_t)i ? H[i] : v;
-        a.matrix[tid] = v;
-        if (a.matrix_host) a.matrix_host[tid] = v;
-    }
-    if (tid == 0 && a.mask_count) {
-        *a.mask_count = n;
-        if (a.mask_count_host) *a.mask_count_host = n;
-    }
-    HG_STAMP(7);
-}
-
-// One launch: workgroup k evaluates hypothesis k; the workgroup that publishes last (a ticket counter) goes on to
-// the refinement with its points still in registers.
-__device__ __forceinline__ void find_homography_wg(const HgArgs &a, const uint32_t k)
-{
-    __shared__ float Hs[9];
-    __shared__ int valid;
-    __shared__ uint32_t red[4];
-    __shared__ uint32_t is_last;
-    const uint32_t tid = threadIdx.x;
-    HG_STAMP(32);
-    const uint32_t n = hg_n(a);
-    HG_STAMP(33);
-    if (tid < 64) {
-        float e;
-        const bool ok = hg_make_hypothesis(a, k, n, tid, e);
-        if (tid < 9) Hs[tid] = ok ? e : (tid % 4u == 0u ? 1.0f : 0.0f);
-        if (tid == 0) valid = ok ? 1 : 0;
-    }
-    HG_STAMP(34);
-    __syncthreads();
-    HG_STAMP(35);
-    float H[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) H[i] = Hs[i];
-    uint32_t cnt = 0;
-    if (valid) {
-        for (uint32_t i = tid; i < n; i += HG_T) {
-            const float2 s = a.src[i], d = a.dst[i];
-            cnt += (hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) ? 1u : 0u;
-        }
-
-    }
-    HG_STAMP(36);
-    cnt = block_sum_u32(cnt, red);
-    // Publish, then take a ticket.  The other workgroups may sit on other XCDs, behind other L2s.  A release / acquire pair at
-    // device scope would do, but on this GPU it is a write-back of the XCD's whole L2 in every workgroup and an invalidation of it
-    // in the last -- with the other camera streams' PyrLK waves living on their tiles in those L2s (57 such operations per
-    // frame).  Instead the ten words a workgroup publishes and the reads of them go past the L2s one by one (device-scope relaxed
-    // atomics: write-through stores, loads that do not hit a stale line), and the order is kept by hand: every thread waits for
-    // its own stores to be acknowledged (the workgroup-scope release of the barrier) before thread 0 takes the ticket.
-    if (tid == 0) __hip_atomic_store(&hg_keys(a)[k], valid ? cnt + 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 9) __hip_atomic_store(&hg_hyp(a)[9 * k + tid], Hs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    HG_STAMP(37);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);       // vmcnt = lgkmcnt = expcnt = 0: the stores above have been acknowledged
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (t == a.K - 1u) ? 1u : 0u;
-        if (t == a.K - 1u) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler: nothing below moves above the ticket
-    HG_STAMP(0);
-    hg_refine(a, n);
-}
-
-__global__ __launch_bounds__(HG_T) void k_find_homography(HgArgs a)
-{
-    find_homography_wg(a, blockIdx.x);
-}
-
-// ---- the same algorithm with the points on chip, in at most 96 registers (arrays of at most HG_NPT * 256 correspondences) ----
+// ---- the kernels: at most 96 registers, so that a workgroup starts beside four PyrLK waves per SIMD --------------------------------
 // Rounds 1 and 2 kept a thread's 16 correspondences in registers (298 in all, 19.8 us alone).  What that kernel cost the OTHER
 // camera streams was its footprint, not its work: a workgroup of four 298-register waves needs a compute unit whose four SIMDs
 // each hold at most two PyrLK waves, so it waits for the other streams' PyrLK launches to drain, and the four hardware queues fall
 // into step -- a do-nothing kernel with that footprint takes the 32-stream bench from 38.3 k to 30.3 k frames/s, the real work
 // another 1.7 k (profiles/r03_homography_dummy_kernels.txt).
-// Four PyrLK waves leave 96 registers per SIMD and 40 KB of LDS per compute unit; this form fits in them:
-//   * a thread's 16 correspondences: destination points in registers (32), source points in LDS (32 KB per workgroup, fetched
-//     straight into it, 16 bytes a lane; the barrier behind the hypothesis stands between those loads and the first read);
+// Four PyrLK waves leave 96 registers per SIMD and 40 KB of LDS per compute unit; both forms below fit in them:
 //   * the refit's 29 binary64 sums in three passes over the inliers (10 + 10 + 9 sums; every sum still sees its products in the
 //     same order), one barrier pair for all three; the current matrix waits in LDS meanwhile;
 //   * the 8 x 8 solve reads the sums from LDS where it needs them (row i on lane i), keeps the pivots and the back-substituted
-//     solution in scalar registers and takes L's columns from the rows by lane reads instead of holding a transposed copy.
-// Results are bit-identical to the kernel above and to the oracle.
+//     solution in scalar registers and takes L's columns from the rows by lane reads instead of holding a transposed copy;
+//   * arrays of at most HG_NPT * 256 correspondences (the tracker graphs'): a thread's 16 correspondences stay ON CHIP -- destination
+//     points in registers (32), source points in LDS (32 KB per workgroup, fetched straight into it, 16 bytes a lane; the barrier
+//     behind the hypothesis stands between those loads and the first read), usable and inlier bits in one register;
+//   * larger arrays: every pass streams the points from memory again (L2 hits) and tests them against the current matrix.
+// Results are bit-identical to the oracle (and to the 298-register kernel of rounds 1 and 2).
 constexpr int HG_NPT = 16;
 static_assert(HG_NPT <= 16, "usable and inlier bits of a thread's points share one 32-bit register");
 
@@ -719,7 +422,9 @@ __device__ __forceinline__ void wave_totals_to_lds(const double (&acc)[N], const
     }
 }
 
-// hg_solve_lanes with the 29 sums read from LDS (w[q][0..3]: the four wave totals of sum q) by the lane that needs them
+// LDL^T solve of the 8x8 normal equations on lanes 0..7 of one wave: lane i owns row i of M and of L; every element sees exactly
+// the operations of the sequential algorithm (oracle/vxoracle_homography.c, hg_fit), in the same order.  The 29 sums are read
+// from LDS (w[q][0..3]: the four wave totals of sum q) by the lane that needs them.
 __device__ __forceinline__ bool hg_solve_lanes_lds(const double (*w)[4], uint32_t lane, double (&h)[8])
 {
     const int i = (int)(lane & 7u);           // lanes 8..63 shadow rows 0..7 (their results are never used)
@@ -803,16 +508,42 @@ struct HgLeanLds {                      // the static part
     uint32_t is_last;
 };
 
-// one pass of the refit over this thread's inliers: a third of the 29 sums, each one the same chain of fused multiply-adds over
-// the points in the same order as in the one-pass form (two passes of 15 + 14 sums do not fit in the registers)
+// One pass of the refit: a third of the 29 sums, each one the same chain of fused multiply-adds over a thread's points in the same
+// order as in a one-pass form (two passes of 15 + 14 sums do not fit in the registers beside sixteen destination points)
 //   pass 0: sums 0..5 (x, y only), 21, 22, 24, 25 (x u, y u, x v, y v);  pass 1: 6..11, 23, 26 (u, v), 27, 28;  pass 2: 12..17, 18..20
+constexpr int HG_PASS_SUMS[3][10] = { { 0, 1, 2, 3, 4, 5, 21, 22, 24, 25 }, { 6, 7, 8, 9, 10, 11, 23, 26, 27, 28 },
+                                      { 12, 13, 14, 15, 16, 17, 18, 19, 20, -1 } };
+template <int PASS> constexpr int hg_pass_n() { return PASS == 2 ? 9 : 10; }
+// ... one correspondence's products
+template <int PASS, int N>
+__device__ __forceinline__ void hg_refit_point(double (&acc)[N], float sx, float sy, float dx, float dy, const HgNorm &nm)
+{
+    // opaque copies: keeps the compiler from hoisting the points' binary64 terms out of the pass (and across passes)
+    asm volatile("" : "+v"(sx), "+v"(sy), "+v"(dx), "+v"(dy));
+    const double x = ((double)sx - nm.cx) * nm.ss, y = ((double)sy - nm.cy) * nm.ss;
+    const double u = ((double)dx - nm.cu) * nm.sd, v = ((double)dy - nm.cv) * nm.sd;
+#define ACC(k, p, q) acc[k] = fma(p, q, acc[k])
+    if (PASS == 0) {
+        ACC(0, x, x); ACC(1, x, y); ACC(2, x, 1.0); ACC(3, y, y); ACC(4, y, 1.0); ACC(5, 1.0, 1.0);
+        ACC(6, x, u); ACC(7, y, u); ACC(8, x, v); ACC(9, y, v);
+    } else if (PASS == 1) {
+        const double q0 = -(x * u), q1 = -(y * u), r0 = -(x * v), r1 = -(y * v);
+        ACC(0, x, q0); ACC(1, x, q1); ACC(2, y, q0); ACC(3, y, q1); ACC(4, 1.0, q0); ACC(5, 1.0, q1);
+        ACC(6, 1.0, u); ACC(7, 1.0, v);
+        ACC(8, q0, u); ACC(8, r0, v); ACC(9, q1, u); ACC(9, r1, v);
+    } else {
+        const double q0 = -(x * u), q1 = -(y * u), r0 = -(x * v), r1 = -(y * v);
+        ACC(0, x, r0); ACC(1, x, r1); ACC(2, y, r0); ACC(3, y, r1); ACC(4, 1.0, r0); ACC(5, 1.0, r1);
+        ACC(6, q0, q0); ACC(6, r0, r0); ACC(7, q0, q1); ACC(7, r0, r1); ACC(8, q1, q1); ACC(8, r1, r1);
+    }
+#undef ACC
+}
+// ... over the inliers among a thread's sixteen on-chip correspondences
 template <int PASS, typename LDS>
 __device__ __forceinline__ void hg_refit_pass(const LDS &L, const float2 (&pd)[HG_NPT], uint32_t inl, const HgNorm &nm,
                                               uint32_t tid, uint32_t lane, uint32_t wv, double (*w)[4])
 {
-    constexpr int N = PASS == 0 ? 10 : (PASS == 1 ? 10 : 9);
-    constexpr int SUM[3][10] = { { 0, 1, 2, 3, 4, 5, 21, 22, 24, 25 }, { 6, 7, 8, 9, 10, 11, 23, 26, 27, 28 },
-                                 { 12, 13, 14, 15, 16, 17, 18, 19, 20, -1 } };
+    constexpr int N = hg_pass_n<PASS>();
     double acc[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) acc[q] = 0.0;
@@ -820,29 +551,46 @@ __device__ __forceinline__ void hg_refit_pass(const LDS &L, const float2 (&pd)[H
     for (int j = 0; j < HG_NPT; ++j) {
         if (!((inl >> j) & 1u)) continue;
         const float2 s = L.src[tid + (uint32_t)j * HG_T];
-        // opaque copies: keeps the compiler from hoisting the points' binary64 terms out of the pass (and across passes)
-        float sx = s.x, sy = s.y, dx = pd[j].x, dy = pd[j].y;
-        asm volatile("" : "+v"(sx), "+v"(sy), "+v"(dx), "+v"(dy));
-        const double x = ((double)sx - nm.cx) * nm.ss, y = ((double)sy - nm.cy) * nm.ss;
-        const double u = ((double)dx - nm.cu) * nm.sd, v = ((double)dy - nm.cv) * nm.sd;
-#define ACC(k, p, q) acc[k] = fma(p, q, acc[k])
-        if (PASS == 0) {
-            ACC(0, x, x); ACC(1, x, y); ACC(2, x, 1.0); ACC(3, y, y); ACC(4, y, 1.0); ACC(5, 1.0, 1.0);
-            ACC(6, x, u); ACC(7, y, u); ACC(8, x, v); ACC(9, y, v);
-        } else if (PASS == 1) {
-            const double q0 = -(x * u), q1 = -(y * u), r0 = -(x * v), r1 = -(y * v);
-            ACC(0, x, q0); ACC(1, x, q1); ACC(2, y, q0); ACC(3, y, q1); ACC(4, 1.0, q0); ACC(5, 1.0, q1);
-            ACC(6, 1.0, u); ACC(7, 1.0, v);
-            ACC(8, q0, u); ACC(8, r0, v); ACC(9, q1, u); ACC(9, r1, v);
-        } else {
-            const double q0 = -(x * u), q1 = -(y * u), r0 = -(x * v), r1 = -(y * v);
-            ACC(0, x, r0); ACC(1, x, r1); ACC(2, y, r0); ACC(3, y, r1); ACC(4, 1.0, r0); ACC(5, 1.0, r1);
-            ACC(6, q0, q0); ACC(6, r0, r0); ACC(7, q0, q1); ACC(7, r0, r1); ACC(8, q1, q1); ACC(8, r1, r1);
-        }
-#undef ACC
+        hg_refit_point<PASS>(acc, s.x, s.y, pd[j].x, pd[j].y, nm);
     }
-    wave_totals_to_lds<N>(acc, SUM[PASS], w, lane, wv);
+    wave_totals_to_lds<N>(acc, HG_PASS_SUMS[PASS], w, lane, wv);
     __builtin_amdgcn_sched_barrier(0);      // the passes one after the other: interleaved they would all hold their sums at once
+}
+// A thread's correspondences in memory -- items t, t + 256, ... in that order -- B at a time with their loads in flight together.
+// Items past n come back as lost points (-1, -1), which nothing counts.  (Left to the compiler, these loops are either unrolled
+// with everything they touch held in registers, 244 of them, or not at all, with one trip to memory per item.)
+template <int B, typename F>
+__device__ __forceinline__ void hg_for_each_point(const HgArgs &a, uint32_t n, uint32_t tid, F &&f)
+{
+    asm volatile("" : "+v"(tid));     // (every walk derives its addresses afresh: hoisted, they are held across the whole refinement)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)      // (interleaved, the counting walks hold two copies of their matrices)
+    for (uint32_t i = tid; i < n; i += (uint32_t)B * HG_T) {
+        float2 s[B], d[B];
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+            const uint32_t idx = i + (uint32_t)j * HG_T, c = min(idx, n - 1u);
+            s[j] = a.src[c];
+            d[j] = a.dst[c];
+            if (idx >= n) s[j] = d[j] = make_float2(-1.0f, -1.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < B; ++j) f(i + (uint32_t)j * HG_T, s[j], d[j]);
+    }
+}
+// ... over the inliers of H among the correspondences in memory
+template <int PASS>
+__device__ __forceinline__ void hg_refit_pass_stream(const HgArgs &a, const float (&H)[9], uint32_t n, const HgNorm &nm,
+                                                     uint32_t tid, uint32_t lane, uint32_t wv, double (*w)[4])
+{
+    constexpr int N = hg_pass_n<PASS>();
+    double acc[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) acc[q] = 0.0;
+    hg_for_each_point<4>(a, n, tid, [&](uint32_t, float2 s, float2 d) {
+        if (hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) hg_refit_point<PASS>(acc, s.x, s.y, d.x, d.y, nm);
+    });
+    wave_totals_to_lds<N>(acc, HG_PASS_SUMS[PASS], w, lane, wv);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <typename LDS>
@@ -854,10 +602,12 @@ __device__ __forceinline__ void hg_refine_lean(const HgArgs &a, LDS &L, const fl
         *a.mask_count = n;
         if (a.mask_count_host) *a.mask_count_host = n;
     }
-    // (keys and hypotheses were published by workgroups on other XCDs: read past this XCD's L2, see find_homography_wg)
+    // all hypotheses travel with the keys, so the winner's matrix is not one more dependent trip to memory
+    // (keys and hypotheses were published by workgroups on other XCDs: read past this XCD's L2, see find_homography_lean_wg)
     const bool pre = a.K <= (uint32_t)HG_KPRE;
     if (pre)
         for (uint32_t e = tid; e < 9u * a.K; e += HG_T) L.hyp_s[e] = __hip_atomic_load(&hg_hyp(a)[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // best hypothesis: most inliers, ties to the lowest index
     unsigned long long best = 0;
     for (uint32_t k = tid; k < a.K; k += HG_T) {
         const uint32_t kk = __hip_atomic_load(&hg_keys(a)[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1036,11 +786,16 @@ __device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_
     }
     HG_STAMP(36);
     cnt = block_sum_u32(valid ? cnt : 0u, L.red);
-    // publish past the L2s, then take a ticket (see find_homography_wg)
+    // Publish, then take a ticket.  The other workgroups may sit on other XCDs, behind other L2s.  A release / acquire pair at
+    // device scope would do, but on this GPU it is a write-back of the XCD's whole L2 in every workgroup and an invalidation of it
+    // in the last -- with the other camera streams' PyrLK waves living on their tiles in those L2s (57 such operations per
+    // frame).  Instead the ten words a workgroup publishes and the reads of them go past the L2s one by one (device-scope relaxed
+    // atomics: write-through stores, loads that do not hit a stale line), and the order is kept by hand: every thread waits for
+    // its own stores to be acknowledged (the workgroup-scope release of the barrier) before thread 0 takes the ticket.
     if (tid == 0) __hip_atomic_store(&hg_keys(a)[k], valid ? cnt + 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 9) __hip_atomic_store(&hg_hyp(a)[9 * k + tid], L.Hs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_waitcnt(0);       // vmcnt = lgkmcnt = expcnt = 0: the stores above have been acknowledged
     __syncthreads();
     if (tid == 0) {
         const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1055,10 +810,160 @@ __device__ __forceinline__ void find_homography_lean_wg(const HgArgs &a, uint32_
     hg_refine_lean(a, L, pd, us, n);
 }
 
+// ---- arrays of any size: the same steps with the correspondences streamed from memory in every pass -----------------------------
+// (the bits a thread's register holds above -- usable, inlier under the current matrix -- are recomputed where they are needed)
+__device__ __forceinline__ void hg_refine_stream(const HgArgs &a, HgLeanLds &L, uint32_t n)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0 && a.mask_count) {
+        *a.mask_count = n;
+        if (a.mask_count_host) *a.mask_count_host = n;
+    }
+    // (keys and hypotheses were published by workgroups on other XCDs: read past this XCD's L2, see find_homography_lean_wg)
+    const bool pre = a.K <= (uint32_t)HG_KPRE;
+    if (pre)
+        for (uint32_t e = tid; e < 9u * a.K; e += HG_T) L.hyp_s[e] = __hip_atomic_load(&hg_hyp(a)[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long best = 0;
+    for (uint32_t k = tid; k < a.K; k += HG_T) {
+        const uint32_t kk = __hip_atomic_load(&hg_keys(a)[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long key = ((unsigned long long)kk << 32) | (unsigned long long)(0xffffffffu - k);
+        best = key > best ? key : best;
+    }
+    uint32_t usable = 0;
+    hg_for_each_point<4>(a, n, tid, [&](uint32_t, float2 s, float2 d) { usable += hg_usable(s, d) ? 1u : 0u; });
+    usable = wave_sum63(usable);
+    best = wave_max63(best);
+    if (lane == 63u) { L.best_w[wv] = best; L.red[wv] = usable; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) best = L.best_w[w] > best ? L.best_w[w] : best;
+    usable = L.red[0] + L.red[1] + L.red[2] + L.red[3];
+    const uint32_t key = (uint32_t)(best >> 32), kbest = 0xffffffffu - (uint32_t)(best & 0xffffffffu);
+
+    // the current matrix lives in LDS (L.Hcur) and is in registers only where it is used
+    if (tid < 9) L.Hcur[tid] = (tid % 4u == 0u) ? 1.0f : 0.0f;
+    uint32_t cnt = 0;
+    if (usable >= 4 && key >= 5) {      // a valid hypothesis with at least 4 inliers
+        cnt = key - 1u;
+        if (tid < 9) L.Hcur[tid] = pre ? L.hyp_s[9 * kbest + tid] : __hip_atomic_load(&hg_hyp(a)[9 * kbest + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // normalisation over all usable correspondences (two passes, interleaved partials)
+        double c4[4] = { 0, 0, 0, 0 };
+        hg_for_each_point<4>(a, n, tid, [&](uint32_t, float2 s, float2 d) {
+            if (hg_usable(s, d)) { c4[0] += (double)s.x; c4[1] += (double)s.y; c4[2] += (double)d.x; c4[3] += (double)d.y; }
+        });
+        block_tree_n<4>(c4, L.wsum);
+        block_tree_read<4>(c4, L.wsum);
+        const double cntd = (double)usable;
+        HgNorm nm;
+        nm.cx = uniform64(c4[0] / cntd); nm.cy = uniform64(c4[1] / cntd); nm.cu = uniform64(c4[2] / cntd); nm.cv = uniform64(c4[3] / cntd);
+        double d2[2] = { 0, 0 };
+        hg_for_each_point<4>(a, n, tid, [&](uint32_t, float2 s, float2 d) {
+            if (hg_usable(s, d)) {
+                d2[0] += fabs((double)s.x - nm.cx) + fabs((double)s.y - nm.cy);
+                d2[1] += fabs((double)d.x - nm.cu) + fabs((double)d.y - nm.cv);
+            }
+        });
+        block_tree_n<2>(d2, L.wsum);
+        block_tree_read<2>(d2, L.wsum);
+        const bool norm_ok = d2[0] > 0.0 && d2[1] > 0.0;
+        nm.ss = uniform64(norm_ok ? cntd / d2[0] : 0.0);
+        nm.sd = uniform64(norm_ok ? cntd / d2[1] : 0.0);
+
+        for (uint32_t r = 0; r < a.max_refine && norm_ok; ++r) {
+            __syncthreads();      // L.Hcur is written; the previous round's readers are done with the sums
+            {
+                float H[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) H[i] = L.Hcur[i];
+                hg_refit_pass_stream<0>(a, H, n, nm, tid, lane, wv, L.wsum);
+                hg_refit_pass_stream<1>(a, H, n, nm, tid, lane, wv, L.wsum);
+                hg_refit_pass_stream<2>(a, H, n, nm, tid, lane, wv, L.wsum);
+            }
+            __syncthreads();
+            if (wv == 0) hg_fit_publish_lds(L.wsum, nm, lane, L.Hnew, &L.fit_ok);
+            __syncthreads();
+            if (!L.fit_ok) break;     // block-uniform
+            float H[9], Hn[9];        // (the current matrix is read again rather than held in registers across the solve)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { H[i] = L.Hcur[i]; Hn[i] = L.Hnew[i]; }
+            uint32_t c = 0, diff = 0;
+            hg_for_each_point<4>(a, n, tid, [&](uint32_t, float2 s, float2 d) {
+                const bool us = hg_usable(s, d);
+                const bool was = us && hg_inlier(H, s, d, a.thr2), now = us && hg_inlier(Hn, s, d, a.thr2);
+                c += now ? 1u : 0u;
+                diff += (was != now) ? 1u : 0u;
+            });
+            c = block_sum_u32(c, L.red);
+            diff = block_sum_u32(diff, L.red);
+            if (c < cnt) break;
+            if (tid < 9) L.Hcur[tid] = L.Hnew[tid];     // (its readers passed the barriers of the two sums above)
+            cnt = c;
+            if (diff == 0) break;
+        }
+    }
+    __syncthreads();      // L.Hcur's last update
+    if (a.mask) {
+        float H[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) H[i] = L.Hcur[i];
+        hg_for_each_point<4>(a, n, tid, [&](uint32_t i, float2 s, float2 d) {
+            if (i < n) a.mask[i] = (cnt != 0 && hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) ? 255 : 0;
+        });
+    }
+    if (tid < 9) {   // transposed on the way out (homography_filter_node.cpp:87-91)
+        const float v = L.Hcur[3u * (tid % 3u) + tid / 3u];
+        a.matrix[tid] = v;
+        if (a.matrix_host) a.matrix_host[tid] = v;
+    }
+}
+
+__device__ __forceinline__ void find_homography_stream_wg(const HgArgs &a, const uint32_t k)
+{
+    __shared__ HgLeanLds L;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = hg_n(a);
+    if (tid < 64) {
+        float e;
+        const bool ok = hg_make_hypothesis(a, k, n, tid, e);
+        if (tid < 9) L.Hs[tid] = ok ? e : (tid % 4u == 0u ? 1.0f : 0.0f);
+        if (tid == 0) L.valid = ok ? 1 : 0;
+    }
+    __syncthreads();
+    float H[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[i] = L.Hs[i];
+    const bool valid = L.valid != 0;
+    uint32_t cnt = 0;
+    if (valid)
+        hg_for_each_point<4>(a, n, tid, [&](uint32_t, float2 s, float2 d) { cnt += (hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) ? 1u : 0u; });
+    cnt = block_sum_u32(cnt, L.red);
+    // publish past the L2s, then take a ticket (see find_homography_lean_wg)
+    if (tid == 0) __hip_atomic_store(&hg_keys(a)[k], valid ? cnt + 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 9) __hip_atomic_store(&hg_hyp(a)[9 * k + tid], L.Hs[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.is_last = (t == a.K - 1u) ? 1u : 0u;
+        if (t == a.K - 1u) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!L.is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // compiler: nothing below moves above the ticket
+    hg_refine_stream(a, L, n);
+}
+
+
 // 48: the attribute counts the unified register file in halves (pyrlk.hip)
 __global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_find_homography_lean(HgArgs a, uint32_t bound)
 {
     find_homography_lean_wg(a, bound, blockIdx.x);
+}
+// ... for arrays of any size
+__global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_find_homography(HgArgs a)
+{
+    find_homography_stream_wg(a, blockIdx.x);
 }
 constexpr uint32_t HG_MERGE_KT = 8, HG_MERGE_KC = 13;   // rounds per block of the merge's walks (four waves, up to 96 registers)
 // ... and with a detector node's merge pass as workgroup 0 (k_find_homography_merge below is the any-size form)
@@ -1077,14 +982,14 @@ __global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_f
 // (merge_cells.hpp) and is long done when the refinement ends; workgroups 1 .. K are the hypotheses.  What a camera stream saves is
 // the merge's launch: its wait for a compute unit with room, its run and the gap in front of it, while the stream's hardware
 // queue is held by the homography's latency chain anyway.
-__global__ __launch_bounds__(HG_T) void k_find_homography_merge(HgArgs a, MergeArgs m)
+__global__ __launch_bounds__(HG_T) __attribute__((amdgpu_num_vgpr(48))) void k_find_homography_merge(HgArgs a, MergeArgs m)
 {
     if (blockIdx.x == 0) {
         VSA_SHORT_KERNEL_PRIORITY();
         merge_compact_wg<(uint32_t)HG_T, HG_MERGE_KT, HG_MERGE_KC>(m);
         return;
     }
-    find_homography_wg(a, blockIdx.x - 1u);
+    find_homography_stream_wg(a, blockIdx.x - 1u);
 }
 
 }  // namespace
