@@ -400,9 +400,20 @@ __device__ __forceinline__ double wave_sum_quad(double a, double b, double c, do
     z = lane_bit1 ? z : y;            // lanes 0, 1 of a quad: a, b; lanes 2, 3: c, d
     return wave_sum_rows(z);          // a..d in lanes 60..63
 }
-// wave totals of sums acc[0..N-1] into w[SUM[q]][wv]: quads, then a pair or a single one
-template <int N>
-__device__ __forceinline__ void wave_totals_to_lds(const double (&acc)[N], const int (&SUM)[10], double (*w)[4], uint32_t lane, uint32_t wv)
+// Which of the 29 sums a refit pass accumulates (hg_refit_point): a function of constants, so that the indices fold into the code
+// (as a table in memory they are scalar loads in the refining workgroup's chain)
+//   pass 0: sums 0..5 (x, y only), 21, 22, 24, 25 (x u, y u, x v, y v);  pass 1: 6..11, 23, 26 (u, v), 27, 28;  pass 2: 12..17, 18..20
+__host__ __device__ constexpr int hg_pass_sum(int pass, int q)
+{
+    return pass == 0 ? (q < 6 ? q : (q == 6 ? 21 : (q == 7 ? 22 : (q == 8 ? 24 : 25))))
+         : pass == 1 ? (q < 6 ? 6 + q : (q == 6 ? 23 : (q == 7 ? 26 : (q == 8 ? 27 : 28))))
+         : 12 + q;
+}
+template <int PASS> constexpr int hg_pass_n() { return PASS == 2 ? 9 : 10; }
+static_assert(hg_pass_sum(0, 9) == 25 && hg_pass_sum(1, 0) == 6 && hg_pass_sum(1, 9) == 28 && hg_pass_sum(2, 8) == 20, "the three passes cover the 29 sums");
+// wave totals of a pass's sums acc[0..N-1] into w[sum][wv]: quads, then a pair or a single one
+template <int PASS, int N>
+__device__ __forceinline__ void wave_totals_to_lds(const double (&acc)[N], double (*w)[4], uint32_t lane, uint32_t wv)
 {
     asm volatile("" : "+v"(lane));    // (the lane-bit masks are made here, not kept in scalar registers across the kernel)
     const bool b0 = lane & 1u, b1 = lane & 2u;
@@ -411,14 +422,14 @@ __device__ __forceinline__ void wave_totals_to_lds(const double (&acc)[N], const
 #pragma unroll
     for (int g = 0; g < Q; ++g) {
         const double z = wave_sum_quad(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3], b0, b1);
-        const int q = b1 ? (b0 ? SUM[4 * g + 3] : SUM[4 * g + 2]) : (b0 ? SUM[4 * g + 1] : SUM[4 * g]);
+        const int q = b1 ? (b0 ? hg_pass_sum(PASS, 4 * g + 3) : hg_pass_sum(PASS, 4 * g + 2)) : (b0 ? hg_pass_sum(PASS, 4 * g + 1) : hg_pass_sum(PASS, 4 * g));
         if (lane >= 60u) w[q][wv] = z;
     }
     if (R == 2) {
         const double z = wave_sum_pair(acc[4 * Q], acc[4 * Q + 1], b0);
-        if (lane >= 62u) w[b0 ? SUM[4 * Q + 1] : SUM[4 * Q]][wv] = z;
+        if (lane >= 62u) w[b0 ? hg_pass_sum(PASS, 4 * Q + 1) : hg_pass_sum(PASS, 4 * Q)][wv] = z;
     } else if (R == 1) {
-        wave_total_to_lds(acc[4 * Q], w, SUM[4 * Q], lane, wv);
+        wave_total_to_lds(acc[4 * Q], w, hg_pass_sum(PASS, 4 * Q), lane, wv);
     }
 }
 
@@ -510,10 +521,7 @@ struct HgLeanLds {                      // the static part
 
 // One pass of the refit: a third of the 29 sums, each one the same chain of fused multiply-adds over a thread's points in the same
 // order as in a one-pass form (two passes of 15 + 14 sums do not fit in the registers beside sixteen destination points)
-//   pass 0: sums 0..5 (x, y only), 21, 22, 24, 25 (x u, y u, x v, y v);  pass 1: 6..11, 23, 26 (u, v), 27, 28;  pass 2: 12..17, 18..20
-constexpr int HG_PASS_SUMS[3][10] = { { 0, 1, 2, 3, 4, 5, 21, 22, 24, 25 }, { 6, 7, 8, 9, 10, 11, 23, 26, 27, 28 },
-                                      { 12, 13, 14, 15, 16, 17, 18, 19, 20, -1 } };
-template <int PASS> constexpr int hg_pass_n() { return PASS == 2 ? 9 : 10; }
+// (which sums a pass takes: hg_pass_sum above)
 // ... one correspondence's products
 template <int PASS, int N>
 __device__ __forceinline__ void hg_refit_point(double (&acc)[N], float sx, float sy, float dx, float dy, const HgNorm &nm)
@@ -553,7 +561,7 @@ __device__ __forceinline__ void hg_refit_pass(const LDS &L, const float2 (&pd)[H
         const float2 s = L.src[tid + (uint32_t)j * HG_T];
         hg_refit_point<PASS>(acc, s.x, s.y, pd[j].x, pd[j].y, nm);
     }
-    wave_totals_to_lds<N>(acc, HG_PASS_SUMS[PASS], w, lane, wv);
+    wave_totals_to_lds<PASS, N>(acc, w, lane, wv);
     __builtin_amdgcn_sched_barrier(0);      // the passes one after the other: interleaved they would all hold their sums at once
 }
 // A thread's correspondences in memory -- items t, t + 256, ... in that order -- B at a time with their loads in flight together.
@@ -589,7 +597,7 @@ __device__ __forceinline__ void hg_refit_pass_stream(const HgArgs &a, const floa
     hg_for_each_point<4>(a, n, tid, [&](uint32_t, float2 s, float2 d) {
         if (hg_usable(s, d) && hg_inlier(H, s, d, a.thr2)) hg_refit_point<PASS>(acc, s.x, s.y, d.x, d.y, nm);
     });
-    wave_totals_to_lds<N>(acc, HG_PASS_SUMS[PASS], w, lane, wv);
+    wave_totals_to_lds<PASS, N>(acc, w, lane, wv);
     __builtin_amdgcn_sched_barrier(0);
 }
 
