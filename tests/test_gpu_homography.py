@@ -48,7 +48,7 @@ def _read_matrix(m):
 
 
 @pytest.mark.parametrize("n,thr,seed,noise,outl", [(4096, 3.0, 0, 0.3, 0.3), (1000, 0.5, 1, 0.1, 0.45), (1000, 3.0, 2, 1.0, 0.6),
-                                                    (37, 3.0, 3, 0.2, 0.2), (9000, 2.0, 4, 0.5, 0.35)])
+                                                    (37, 3.0, 3, 0.2, 0.2), (9000, 2.0, 4, 0.5, 0.35), (150001, 1.5, 5, 0.4, 0.4)])
 @pytest.mark.parametrize("large_array_kernels", [False, True])
 def test_immediate_matches_oracle(ctx, monkeypatch, n, thr, seed, noise, outl, large_array_kernels):
     # arrays of capacity <= 4096 take the on-chip kernel (points in registers + LDS, 96 registers); the switch forces the any-size kernel
